@@ -1,0 +1,110 @@
+"""Deterministic synthetic weights and inputs (no checkpoints ship with this repo).
+
+Every tensor is drawn from a numpy PCG64 stream seeded by (seed, crc32(name)), so the
+same name always yields the same values on any machine and independent of creation
+order.  Parameter names follow the checkpoint layout of the reference's
+``UnifiedWanWithMixedConditionModel`` (``wan_model.*``, ``vlm_norm.*``, ``vlm_proj.*``,
+``visual_context_adapter.*``; reference: omnivideo/modules/unified_model.py:79-90,
+omnivideo/modules/model.py:118-123,202-216,273-276,384-401).
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rng(seed, name):
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+
+
+def randn(name, shape, seed=0, scale=1.0):
+    a = _rng(seed, name).standard_normal(size=tuple(shape), dtype=np.float32)
+    return torch.from_numpy(a * np.float32(scale))
+
+
+def uniform(name, shape, bound, seed=0):
+    a = _rng(seed, name).random(size=tuple(shape), dtype=np.float32)
+    return torch.from_numpy((a * 2 - 1) * np.float32(bound))
+
+
+def dit_config(name="1.3B", **over):
+    """Architecture hyper-parameters (reference: omnivideo/configs/wan_t2v_1_3B.py:19-40,
+    wan_t2v_A14B.py:19-42, shared_config.py:10)."""
+    base = dict(patch_size=(1, 2, 2), in_dim=16, out_dim=16, freq_dim=256, text_dim=4096,
+                text_len=512, eps=1e-6, vlm_in_dim=2048,
+                visual_patch_size=(1, 4, 4), use_visual_context_adapter=True)
+    if name == "1.3B":
+        base.update(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30)
+    elif name == "A14B":
+        base.update(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40)
+    elif name == "tiny":
+        base.update(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=128,
+                    vlm_in_dim=96, text_len=48)
+    else:
+        raise ValueError(name)
+    base.update(over)
+    return base
+
+
+def _linear(sd, prefix, out_f, in_f, seed, bias=True):
+    bound = 1.0 / math.sqrt(in_f)
+    sd[prefix + ".weight"] = uniform(prefix + ".weight", (out_f, in_f), bound, seed)
+    if bias:
+        sd[prefix + ".bias"] = uniform(prefix + ".bias", (out_f,), bound, seed)
+
+
+def _norm_weight(sd, name, dim, seed):
+    sd[name] = 1.0 + randn(name, (dim,), seed, 0.1)
+
+
+def make_unified_state_dict(cfg, seed=0):
+    """fp32 state dict for the mixed-condition DiT."""
+    C, F, T = cfg["dim"], cfg["ffn_dim"], cfg["text_dim"]
+    pt, ph, pw = cfg["patch_size"]
+    sd = {}
+    w = "wan_model."
+    fan = cfg["in_dim"] * pt * ph * pw
+    sd[w + "patch_embedding.weight"] = uniform(w + "patch_embedding.weight",
+                                               (C, cfg["in_dim"], pt, ph, pw),
+                                               1 / math.sqrt(fan), seed)
+    sd[w + "patch_embedding.bias"] = uniform(w + "patch_embedding.bias", (C,),
+                                             1 / math.sqrt(fan), seed)
+    _linear(sd, w + "text_embedding.0", C, T, seed)
+    _linear(sd, w + "text_embedding.2", C, C, seed)
+    _linear(sd, w + "time_embedding.0", C, cfg["freq_dim"], seed)
+    _linear(sd, w + "time_embedding.2", C, C, seed)
+    _linear(sd, w + "time_projection.1", 6 * C, C, seed)
+    for i in range(cfg["num_layers"]):
+        b = f"{w}blocks.{i}."
+        for att in ("self_attn", "cross_attn"):
+            for p in "qkvo":
+                _linear(sd, f"{b}{att}.{p}", C, C, seed)
+            _norm_weight(sd, f"{b}{att}.norm_q.weight", C, seed)
+            _norm_weight(sd, f"{b}{att}.norm_k.weight", C, seed)
+        _norm_weight(sd, b + "norm3.weight", C, seed)
+        sd[b + "norm3.bias"] = randn(b + "norm3.bias", (C,), seed, 0.1)
+        _linear(sd, b + "ffn.0", F, C, seed)
+        _linear(sd, b + "ffn.2", C, F, seed)
+        sd[b + "modulation"] = randn(b + "modulation", (1, 6, C), seed, C ** -0.5)
+    _linear(sd, w + "head.head", cfg["out_dim"] * pt * ph * pw, C, seed)
+    sd[w + "head.modulation"] = randn(w + "head.modulation", (1, 2, C), seed, C ** -0.5)
+    _norm_weight(sd, "vlm_norm.weight", cfg["vlm_in_dim"], seed)
+    _linear(sd, "vlm_proj", T, cfg["vlm_in_dim"], seed)
+    if cfg.get("use_visual_context_adapter", True):
+        vt, vh, vw = cfg["visual_patch_size"]
+        fan = cfg["in_dim"] * vt * vh * vw
+        v = "visual_context_adapter."
+        sd[v + "patch_embedding.weight"] = uniform(v + "patch_embedding.weight",
+                                                   (C, cfg["in_dim"], vt, vh, vw),
+                                                   1 / math.sqrt(fan), seed)
+        sd[v + "patch_embedding.bias"] = uniform(v + "patch_embedding.bias", (C,),
+                                                 1 / math.sqrt(fan), seed)
+        _linear(sd, v + "projection", T, C, seed)
+    return sd
+
+
+def make_special_tokens(cfg, seed=0):
+    """Four learned delimiter rows (reference: unified_model.py:249-252)."""
+    return {k: randn("special." + k, (1, cfg["text_dim"]), seed)
+            for k in ("<img_st>", "<img_ed>", "<prp_st>", "<prp_ed>")}
