@@ -1,0 +1,141 @@
+/* libomnihip - C ABI of the MI355X (gfx950) kernels behind the Omni-Video 2 sampling path.
+ *
+ * The reference has no FFI layer of its own: its hot path crosses into native code only
+ * through Python entry points of third-party wheels (flash_attn, torch/cuDNN/cuBLAS).
+ * Each entry point below names the reference call site (path:line under the reference
+ * tree) whose device work it replaces.
+ *
+ * Conventions
+ *   - every pointer is a borrowed DEVICE pointer (bf16 tensors are raw uint16_t bit
+ *     patterns); nothing is retained after the call returns; no entry point allocates,
+ *     frees or synchronises, so all of them may be captured into a HIP graph;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - return value 0 = launched; non-zero = rejected before any launch, with the reason
+ *     in ovd_last_error() (thread-local, valid until the next call on that thread);
+ *   - strides (`ld*`, `*_bs`) are in ELEMENTS.
+ */
+#ifndef OMNIHIP_H
+#define OMNIHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ovd_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int ovd_abi_version(void);
+
+/* LayerNorm over the last dim (fp32 statistics, biased variance, eps inside the sqrt),
+ * optional bf16 affine (weight, bias both or neither), optional AdaLN modulation
+ * y = n * (1 + scale[c]) + shift[c] (fp32 rows of length C, both or neither).
+ * round_norm != 0 rounds the normalised value to bf16 before the modulation (the case of
+ * a bf16 input tensor).  C must be a multiple of 256.
+ * Replaces WanLayerNorm.forward (omnivideo/modules/model.py:92-97) fused with the
+ * modulation in WanAttentionBlock.forward (model.py:243,250,252) and Head.forward
+ * (model.py:287-289); also nn.LayerNorm in VisualContextAdapter.forward
+ * (omnivideo/modules/visual_context_adapter.py:111,114). */
+int ovd_layernorm_modulate_bf16(const float* x, int64_t ldx, const float* shift, const float* scale,
+                                const uint16_t* weight, const uint16_t* bias, uint16_t* out, int64_t ldo,
+                                int M, int C, float eps, int round_norm, void* stream);
+int ovd_layernorm_modulate_f32(const float* x, int64_t ldx, const float* shift, const float* scale,
+                               const uint16_t* weight, const uint16_t* bias, float* out, int64_t ldo,
+                               int M, int C, float eps, int round_norm, void* stream);
+
+/* RMSNorm over the FULL row (all heads) with bf16 weight, then optional 3-axis
+ * interleaved-pair rotary embedding, bf16 in / bf16 out (in-place allowed).
+ * rope: float2 (cos,sin) table [3][rope_rows][D/2] or NULL for no rotation; the token
+ * index of a row is (row % rows_per_sample) + tok_offset, decomposed over the patch grid
+ * (gf,gh,gw); rows with token index >= n_rope are not rotated.  weight == NULL skips
+ * the normalisation (rotation only).
+ * Replaces WanRMSNorm.forward (model.py:76-84) at model.py:137-138,169-170 and
+ * unified_model.py:201, plus rope_apply (model.py:37-65; sequence-parallel variant
+ * omnivideo/distributed/full_sequence_parallel.py:22-60 via tok_offset). */
+int ovd_rmsnorm_rope_bf16(const uint16_t* in, int64_t ldi, const uint16_t* weight, const float* rope,
+                          int rope_rows, uint16_t* out, int64_t ldo, int M, int C, int head_dim, float eps,
+                          int rows_per_sample, int tok_offset, int n_rope, int gf, int gh, int gw,
+                          void* stream);
+
+/* out = epilogue(A[M,K] * W[N,K]^T + bias[N]), bf16 operands, fp32 accumulation.
+ * epilogue 0: bf16 out; 1: bf16 out of tanh-GELU(bf16-rounded pre-activation);
+ * 2: fp32 out holding the bf16-rounded value; 3: fp32 in-place residual
+ * out += bf16-rounded(acc + bias) * gate[n] (gate fp32 [N] or NULL for 1).
+ * K % 64 == 0, N % 128 == 0.  bias may be NULL.
+ * Replaces nn.Linear under bf16 autocast at model.py:137-139,153,169-171,178,
+ * 211-213,386-388, unified_model.py:202, visual_context_adapter.py:112, the Conv3d patch
+ * embeddings (model.py:455, visual_context_adapter.py:101) after ovd_patchify, and the
+ * gated residual adds of model.py:245-254. */
+int ovd_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
+                  void* out, int64_t ldo, const float* gate, int M, int N, int K, int epilogue,
+                  void* stream);
+
+/* softmax(q k^T * softmax_scale) v, non-causal, per (batch, head); head_dim must be 128.
+ * q [B,Lq,N,D], k/v [B,Lk,N,D], out [B,Lq,N,D], all bf16; *_ld = elements between
+ * consecutive tokens, *_bs = elements between batch entries.  Keys at index >= k_len
+ * are masked out (0 < k_len <= Lk).
+ * Replaces flash_attn(_interface).flash_attn_varlen_func as called from
+ * omnivideo/modules/attention.py:96-130 (via model.py:144-149 and model.py:174). */
+int ovd_flash_attn_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, int B,
+                            int Lq, int Lk, int N, int head_dim, int k_len, int64_t q_ld, int64_t k_ld,
+                            int64_t v_ld, int64_t o_ld, int64_t q_bs, int64_t k_bs, int64_t v_bs,
+                            int64_t o_bs, float softmax_scale, void* stream);
+
+/* [Cin,T,H,W] (fp32, or bf16 when lat_is_bf16) -> bf16 rows [f*h*w, Cin*pt*ph*pw] in
+ * (f,h,w) token order and (cin,pt,ph,pw) column order, ready for ovd_gemm_bf16 against
+ * the flattened Conv3d weight.  Replaces the im2col half of nn.Conv3d with
+ * kernel = stride = patch (model.py:384-385,455-458; visual_context_adapter.py:52-54). */
+int ovd_patchify(const void* lat, int lat_is_bf16, uint16_t* rows, int Cin, int T, int H, int W, int pt,
+                 int ph, int pw, void* stream);
+
+/* out[0:dim/2] = cos(t * 10000^(-i/(dim/2))), out[dim/2:] = sin(...), evaluated in
+ * float64, stored fp32; t = timesteps[step_ptr ? *step_ptr : step] (float64 table: the
+ * reference converts its integer timesteps with position.type(torch.float64)).
+ * Replaces sinusoidal_embedding_1d (model.py:13-23) at model.py:473-474. */
+int ovd_time_sinusoid(const double* timesteps, const int* step_ptr, int step, float* out, int dim,
+                      void* stream);
+
+/* y[N] = act(x[K]) . W[N,K] + b[N] in fp32 on bf16 weights; silu_in applies SiLU to x
+ * first.  Replaces time_embedding / time_projection (model.py:390-392,472-475), which
+ * the reference evaluates under a float32 autocast for every token although the
+ * timestep is one scalar per sample. */
+int ovd_gemv_f32(const float* x, const uint16_t* W, const uint16_t* b, float* y, int N, int K,
+                 int silu_in, void* stream);
+
+/* out[l][i] = float(params[l][i]) + e0[i], i < n6c = 6*C, for every layer l: the
+ * per-block modulation add (model.py:237-238).  params = device array of n_layers
+ * device pointers. */
+int ovd_modulation_table(const uint16_t* const* params, const float* e0, float* out, int n_layers,
+                         int n6c, void* stream);
+/* out[j][c] = float(mod[j][c]) + e[c], j in {0,1}: Head.forward's modulation
+ * (model.py:286). */
+int ovd_head_modulation(const uint16_t* mod, const float* e, float* out, int C, void* stream);
+
+/* Head projection in exact fp32 fused with the unpatchify scatter:
+ * out[c][f*pt+p][h*ph+q][w*pw+r] = y[tok(f,h,w)] . W[(p,q,r,c)] + bias, with
+ * out_dim*pt*ph*pw == 64.  y is the normalised + modulated fp32 activation [n_tok.., C].
+ * Replaces Head.head under float32 autocast (model.py:285-289) and WanModel.unpatchify
+ * (model.py:526-549). */
+int ovd_head_unpatchify(const float* y, int64_t ldy, const uint16_t* W, const uint16_t* bias, float* out,
+                        int n_tok, int C, int Cout, int pt, int ph, int pw, int gf, int gh, int gw,
+                        void* stream);
+
+/* One sampling step on n latent elements:
+ *   v = uncond + guide * (cond - uncond)                 (x2x_gen_unified.py:484)
+ *   x0 = sample - sigma * v                              (fm_solvers_unipc.py:316-322)
+ *   corrector (from step 1 on), history shift, predictor (fm_solvers_unipc.py:690-729)
+ * sample / last_sample are in the latent dtype (bf16 when sample_is_bf16, else fp32) and
+ * are updated in place; m1/m2 are the fp32 x0 history (newest / older).  coef is the
+ * host-built table [steps][16] (row layout: csrc/sampler.hip); the row index is
+ * *step_ptr when step_ptr is non-NULL, else `step`. */
+int ovd_cfg_unipc_step(const float* cond, const float* uncond, void* sample, void* last_sample, float* m1,
+                       float* m2, const float* coef, float guide_scale, const int* step_ptr, int step,
+                       int64_t n, int sample_is_bf16, void* stream);
+#define OVD_UNIPC_COEF_STRIDE 16
+
+/* *step_ptr += 1 on the device (advances the step counter inside a captured graph). */
+int ovd_step_advance(int* step_ptr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

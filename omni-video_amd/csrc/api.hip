@@ -1,0 +1,137 @@
+// extern "C" surface of libomnihip: thin argument adapters over the kernel launchers.
+#include <stdarg.h>
+
+#include "../../include/omnihip.h"
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ovd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ovd_impl_ln_bf16(const float*, long, const float*, const float*, const bf16_t*, const bf16_t*, bf16_t*, long,
+                     int, int, float, int, hipStream_t);
+int ovd_impl_ln_f32(const float*, long, const float*, const float*, const bf16_t*, const bf16_t*, float*, long, int,
+                    int, float, int, hipStream_t);
+int ovd_impl_rmsnorm_rope(const bf16_t*, long, const bf16_t*, const float*, int, bf16_t*, long, int, int, int, float,
+                          int, int, int, int, int, int, hipStream_t);
+int ovd_impl_gemm_bf16(const bf16_t*, long, const bf16_t*, long, const bf16_t*, void*, long, const float*, int, int,
+                       int, int, hipStream_t);
+int ovd_impl_attn_fwd(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, long, long,
+                      long, long, long, long, long, long, float, hipStream_t);
+int ovd_impl_patchify(const void*, int, bf16_t*, int, int, int, int, int, int, int, hipStream_t);
+int ovd_impl_time_sinusoid(const double*, const int*, int, float*, int, hipStream_t);
+int ovd_impl_gemv_f32(const float*, const bf16_t*, const bf16_t*, float*, int, int, int, hipStream_t);
+int ovd_impl_modulation(const bf16_t* const*, const float*, float*, int, int, hipStream_t);
+int ovd_impl_head_modulation(const bf16_t*, const float*, float*, int, hipStream_t);
+int ovd_impl_head_unpatchify(const float*, long, const bf16_t*, const bf16_t*, float*, int, int, int, int, int, int,
+                             int, int, int, hipStream_t);
+int ovd_impl_cfg_unipc_step(const float*, const float*, void*, void*, float*, float*, const float*, float,
+                            const int*, int, long, int, hipStream_t);
+int ovd_impl_step_advance(int*, hipStream_t);
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define NONNULL(p) OVD_REQUIRE((p) != nullptr, "%s: null pointer argument '%s'", __func__, #p)
+
+extern "C" {
+
+const char* ovd_last_error(void) { return g_err; }
+int ovd_abi_version(void) { return 1; }
+
+int ovd_layernorm_modulate_bf16(const float* x, int64_t ldx, const float* shift, const float* scale,
+                                const uint16_t* weight, const uint16_t* bias, uint16_t* out, int64_t ldo, int M,
+                                int C, float eps, int round_norm, void* stream) {
+    NONNULL(x); NONNULL(out);
+    OVD_REQUIRE(M >= 0 && C > 0, "layernorm: bad shape M=%d C=%d", M, C);
+    return ovd_impl_ln_bf16(x, ldx, shift, scale, weight, bias, out, ldo, M, C, eps, round_norm, ST(stream));
+}
+
+int ovd_layernorm_modulate_f32(const float* x, int64_t ldx, const float* shift, const float* scale,
+                               const uint16_t* weight, const uint16_t* bias, float* out, int64_t ldo, int M, int C,
+                               float eps, int round_norm, void* stream) {
+    NONNULL(x); NONNULL(out);
+    OVD_REQUIRE(M >= 0 && C > 0, "layernorm: bad shape M=%d C=%d", M, C);
+    return ovd_impl_ln_f32(x, ldx, shift, scale, weight, bias, out, ldo, M, C, eps, round_norm, ST(stream));
+}
+
+int ovd_rmsnorm_rope_bf16(const uint16_t* in, int64_t ldi, const uint16_t* weight, const float* rope, int rope_rows,
+                          uint16_t* out, int64_t ldo, int M, int C, int head_dim, float eps, int rows_per_sample,
+                          int tok_offset, int n_rope, int gf, int gh, int gw, void* stream) {
+    NONNULL(in); NONNULL(out);
+    OVD_REQUIRE(weight != nullptr || rope != nullptr, "rmsnorm: neither weight nor rope given");
+    OVD_REQUIRE(M >= 0 && C > 0, "rmsnorm: bad shape M=%d C=%d", M, C);
+    return ovd_impl_rmsnorm_rope(in, ldi, weight, rope, rope_rows, out, ldo, M, C, head_dim, eps, rows_per_sample,
+                                 tok_offset, n_rope, gf, gh, gw, ST(stream));
+}
+
+int ovd_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias, void* out,
+                  int64_t ldo, const float* gate, int M, int N, int K, int epilogue, void* stream) {
+    NONNULL(A); NONNULL(W); NONNULL(out);
+    OVD_REQUIRE(M >= 0, "gemm: negative M");
+    return ovd_impl_gemm_bf16(A, lda, W, ldw, bias, out, ldo, gate, M, N, K, epilogue, ST(stream));
+}
+
+int ovd_flash_attn_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, int B, int Lq,
+                            int Lk, int N, int head_dim, int k_len, int64_t q_ld, int64_t k_ld, int64_t v_ld,
+                            int64_t o_ld, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                            float softmax_scale, void* stream) {
+    NONNULL(q); NONNULL(k); NONNULL(v); NONNULL(out);
+    return ovd_impl_attn_fwd(q, k, v, out, B, Lq, Lk, N, head_dim, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs,
+                             o_bs, softmax_scale, ST(stream));
+}
+
+int ovd_patchify(const void* lat, int lat_is_bf16, uint16_t* rows, int Cin, int T, int H, int W, int pt, int ph,
+                 int pw, void* stream) {
+    NONNULL(lat); NONNULL(rows);
+    return ovd_impl_patchify(lat, lat_is_bf16, rows, Cin, T, H, W, pt, ph, pw, ST(stream));
+}
+
+int ovd_time_sinusoid(const double* timesteps, const int* step_ptr, int step, float* out, int dim, void* stream) {
+    NONNULL(timesteps); NONNULL(out);
+    OVD_REQUIRE(step_ptr != nullptr || step >= 0, "time_sinusoid: negative step");
+    return ovd_impl_time_sinusoid(timesteps, step_ptr, step, out, dim, ST(stream));
+}
+
+int ovd_gemv_f32(const float* x, const uint16_t* W, const uint16_t* b, float* y, int N, int K, int silu_in,
+                 void* stream) {
+    NONNULL(x); NONNULL(W); NONNULL(y);
+    return ovd_impl_gemv_f32(x, W, b, y, N, K, silu_in, ST(stream));
+}
+
+int ovd_modulation_table(const uint16_t* const* params, const float* e0, float* out, int n_layers, int n6c,
+                         void* stream) {
+    NONNULL(params); NONNULL(e0); NONNULL(out);
+    OVD_REQUIRE(n_layers >= 0 && n_layers <= 65535 && n6c > 0, "modulation: bad sizes");
+    return ovd_impl_modulation(params, e0, out, n_layers, n6c, ST(stream));
+}
+
+int ovd_head_modulation(const uint16_t* mod, const float* e, float* out, int C, void* stream) {
+    NONNULL(mod); NONNULL(e); NONNULL(out);
+    return ovd_impl_head_modulation(mod, e, out, C, ST(stream));
+}
+
+int ovd_head_unpatchify(const float* y, int64_t ldy, const uint16_t* W, const uint16_t* bias, float* out, int n_tok,
+                        int C, int Cout, int pt, int ph, int pw, int gf, int gh, int gw, void* stream) {
+    NONNULL(y); NONNULL(W); NONNULL(out);
+    return ovd_impl_head_unpatchify(y, ldy, W, bias, out, n_tok, C, Cout, pt, ph, pw, gf, gh, gw, ST(stream));
+}
+
+int ovd_cfg_unipc_step(const float* cond, const float* uncond, void* sample, void* last_sample, float* m1, float* m2,
+                       const float* coef, float guide_scale, const int* step_ptr, int step, int64_t n,
+                       int sample_is_bf16, void* stream) {
+    NONNULL(cond); NONNULL(uncond); NONNULL(sample); NONNULL(last_sample); NONNULL(m1); NONNULL(m2); NONNULL(coef);
+    OVD_REQUIRE(step_ptr != nullptr || step >= 0, "cfg_unipc: negative step");
+    return ovd_impl_cfg_unipc_step(cond, uncond, sample, last_sample, m1, m2, coef, guide_scale, step_ptr, step, n,
+                                   sample_is_bf16, ST(stream));
+}
+
+int ovd_step_advance(int* step_ptr, void* stream) {
+    NONNULL(step_ptr);
+    return ovd_impl_step_advance(step_ptr, ST(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,235 @@
+// Flash-style attention forward for head_dim 128, bf16 in / fp32 accumulate / bf16 out,
+// non-causal, keys limited to k_len (tail masked).  Replaces the flash_attn_varlen_func
+// call sites of the reference (omnivideo/modules/attention.py:96-130) for the shapes the
+// DiT uses: self-attention (Lq = Lk = padded sequence, k_len = real tokens;
+// model.py:144-149) and cross-attention over the padded context (model.py:174).
+//
+// Work split: one workgroup = 8 waves = 256 query rows of one (batch, head); each wave
+// owns 32 query rows.  K/V tiles of 64 keys are staged HBM -> registers -> LDS (two
+// buffers; the global loads for tile t+1 are issued before tile t's MFMAs and written
+// to LDS after them, so HBM latency hides under compute).
+//
+// S^T = K Q^T is computed with the key on the MFMA row axis (v_mfma_f32_32x32x16_bf16),
+// so every lane holds 32 scores of ONE query column: the row max / row sum are
+// in-register reductions plus one cross-half exchange, and the exponentiated scores
+// are already laid out as the B operand of O^T += V^T P^T (no LDS round trip for P).
+// V^T fragments come from the row-major V tile through ds_read_b64_tr_b16.
+// LDS images are XOR-swizzled per 16-byte chunk so both the b128 row reads of K and
+// the transposed reads of V are bank-conflict free.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 128;        // head dim
+constexpr int BQ = 256;        // query rows per workgroup
+constexpr int BKV = 64;        // keys per tile
+constexpr int KV_TILE_BYTES = BKV * HD * 2;   // 16 KiB
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
+
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+__device__ __forceinline__ int v_off(int row, int chunk) { return row * 256 + ((chunk ^ ((row & 3) << 2)) << 4); }
+
+__global__ void __launch_bounds__(512, 2)
+attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,
+                long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2] | V[2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * BQ + wave * 32;
+
+    const bf16_t* Qb = Q + b * q_bs + (long)head * HD;
+    const bf16_t* Kb = K + b * k_bs + (long)head * HD;
+    const bf16_t* Vb = V + b * v_bs + (long)head * HD;
+
+    // Q fragments: B operand of S^T = K Q^T; lane (query l31, half hi) holds d = 16*ks + 8*hi + j
+    bf16x8 qf[8];
+    {
+        int qr = q0 + l31;
+        qr = qr < Lq ? qr : Lq - 1;
+        const bf16_t* qp = Qb + (long)qr * q_ld + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+
+    f32x16 o_acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o_acc[i][j] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int nt = (k_len + BKV - 1) / BKV;
+
+    // staging map: 512 threads x 2 chunks of 16 B per operand tile (64 rows x 16 chunks)
+    uint4 kreg[2], vreg[2];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 512;
+            const int r = id >> 4, c = id & 15;
+            int kr = t * BKV + r;
+            kr = kr < Lk ? kr : Lk - 1;
+            kreg[i] = *reinterpret_cast<const uint4*>(Kb + (long)kr * k_ld + c * 8);
+            vreg[i] = *reinterpret_cast<const uint4*>(Vb + (long)kr * v_ld + c * 8);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* sk = smem + buf * KV_TILE_BYTES;
+        char* sv = smem + (2 + buf) * KV_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 512;
+            const int r = id >> 4, c = id & 15;
+            *reinterpret_cast<uint4*>(sk + k_off(r, c)) = kreg[i];
+            *reinterpret_cast<uint4*>(sv + v_off(r, c)) = vreg[i];
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        const char* sk = smem + buf * KV_TILE_BYTES;
+        const char* sv = smem + (2 + buf) * KV_TILE_BYTES;
+        if (t + 1 < nt) load_tile(t + 1);
+
+        // ---- S^T[key][query] for 64 keys: two 32-key blocks x 8 k-steps over d
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s[kb][j] = 0.f;
+            const int key = kb * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(key, 2 * ks + hi));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        // s[kb][r] is the score of key kb*32 + (r&3) + 8*(r>>2) + 4*hi against query l31
+        if (t == nt - 1 && (t + 1) * BKV > k_len) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= k_len) s[kb][r] = -INFINITY;
+                }
+        }
+
+        // ---- online softmax (per query = per lane column; halves hold disjoint keys)
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * scale_log2);
+        const float mb = m_new * scale_log2;
+        m_run = m_new;
+        float rs = 0.f;
+        bf16x8 pf[4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = exp2f(s[kb][r] * scale_log2 - mb);
+                rs += p[r];
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = pack_bf2(p[8 * h2 + 2 * j], p[8 * h2 + 2 * j + 1]);
+                pf[kb * 2 + h2] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+        }
+        l_run = l_run * alpha + rs;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) o_acc[i][j] *= alpha;
+        }
+
+        // ---- O^T[d][query] += V^T[d][key] P^T[key][query]; 4 k-steps of 16 keys, 4 d-blocks of 32
+        // element j of the P fragment of k-step st is key 16*st + 8*(j>>2) + 4*hi + (j&3)
+        {
+            const int g = lane >> 4, i16 = lane & 15, qd = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int krow = 16 * st + 4 * (g >> 1) + qd;    // this lane's address row (first read)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_b4_ptr)(sv + v_off(krow, chunk) + 8 * (pp & 1)));
+                    const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_b4_ptr)(sv + v_off(krow + 8, chunk) + 8 * (pp & 1)));
+                    const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi4);
+                    const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo2.x, lo2.y, hi2.x, hi2.y));
+                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o_acc[db], 0, 0, 0);
+                }
+            }
+        }
+
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane (query l31, half hi) holds d = db*32 + 8*(r>>2) + 4*hi + (r&3)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + l31;
+    if (qr < Lq) {
+        bf16_t* op = O + b * o_bs + (long)qr * o_ld + (long)head * HD + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(o_acc[db][4 * g4 + 0] * inv, o_acc[db][4 * g4 + 1] * inv);
+                w.y = pack_bf2(o_acc[db][4 * g4 + 2] * inv, o_acc[db][4 * g4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + db * 32 + 8 * g4) = w;
+            }
+    }
+}
+
+}  // namespace
+
+// q [B,Lq,N,128], k/v [B,Lk,N,128], out [B,Lq,N,128]; *_ld = elements between
+// consecutive tokens, *_bs = elements between batch entries (so the fused QKV
+// projection buffer can be addressed in place).  Keys at index >= k_len are masked.
+int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Lq, int Lk,
+                      int N, int D, int k_len, long q_ld, long k_ld, long v_ld, long o_ld, long q_bs, long k_bs,
+                      long v_bs, long o_bs, float softmax_scale, hipStream_t st) {
+    OVD_REQUIRE(D == HD, "attention: head_dim %d not supported (only 128)", D);
+    OVD_REQUIRE(B > 0 && N > 0 && Lq > 0 && Lk > 0, "attention: empty problem B=%d N=%d Lq=%d Lk=%d", B, N, Lq, Lk);
+    OVD_REQUIRE(k_len > 0 && k_len <= Lk, "attention: k_len=%d outside (0, Lk=%d]", k_len, Lk);
+    OVD_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && v_ld % 8 == 0 && o_ld % 4 == 0,
+                "attention: token strides must keep 16-byte alignment");
+    OVD_REQUIRE(q_ld >= (long)N * D && k_ld >= (long)N * D && v_ld >= (long)N * D && o_ld >= (long)N * D,
+                "attention: token stride shorter than N*D");
+    static bool attr_set = false;
+    const size_t lds = 4 * KV_TILE_BYTES;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            OVD_FAIL("attention: cannot reserve %zu bytes of LDS", lds);
+        attr_set = true;
+    }
+    dim3 grid(ceil_div(Lq, BQ), N, B), blk(512);
+    const float scale_log2 = softmax_scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, blk, lds, st, q, k, v, out, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld,
+                       q_bs, k_bs, v_bs, o_bs, scale_log2);
+    OVD_CHECK_LAUNCH("attn_fwd");
+    return 0;
+}

@@ -1,0 +1,59 @@
+// Shared device/host helpers for libomnihip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bit pattern
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 (one MFMA A/B fragment)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- error channel -------------------------------------------------------------
+void ovd_set_error(const char* fmt, ...);
+#define OVD_FAIL(...)          \
+    do {                       \
+        ovd_set_error(__VA_ARGS__); \
+        return 1;              \
+    } while (0)
+#define OVD_REQUIRE(cond, ...) \
+    do {                       \
+        if (!(cond)) OVD_FAIL(__VA_ARGS__); \
+    } while (0)
+#define OVD_CHECK_LAUNCH(name)                                              \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) OVD_FAIL("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even through the hardware convert (v_cvt_pk_bf16_f32); NaN stays NaN
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    f32x2_ v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,231 @@
+"""ctypes binding of libomnihip.so (the C-ABI declared in include/omnihip.h).
+
+There is no fallback: if the library is missing or an entry point is rejected the call
+raises.  Tensors are borrowed for the duration of the call; every launch goes to torch's
+current HIP stream so the calls compose with torch ops and can be graph-captured.
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libomnihip.so")
+_lib = None
+
+_i, _l, _f, _p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+SIGNATURES = {
+    "ovd_layernorm_modulate_bf16": [_p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _f, _i, _p],
+    "ovd_layernorm_modulate_f32": [_p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _f, _i, _p],
+    "ovd_rmsnorm_rope_bf16": [_p, _l, _p, _p, _i, _p, _l, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p],
+    "ovd_gemm_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _p],
+    "ovd_flash_attn_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p],
+    "ovd_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ovd_time_sinusoid": [_p, _p, _i, _p, _i, _p],
+    "ovd_gemv_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "ovd_modulation_table": [_p, _p, _p, _i, _i, _p],
+    "ovd_head_modulation": [_p, _p, _p, _i, _p],
+    "ovd_head_unpatchify": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ovd_cfg_unipc_step": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
+    "ovd_step_advance": [_p, _p],
+}
+
+EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_RESID = 0, 1, 2, 3
+UNIPC_COEF_STRIDE = 16
+
+
+def lib():
+    """Loads libomnihip.so once; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} not found: build it with `make -C omni-video_amd/csrc` "
+                "(or __graft_entry__.build()); there is no non-HIP fallback")
+        L = ctypes.CDLL(_LIB_PATH)
+        L.ovd_last_error.restype = ctypes.c_char_p
+        L.ovd_abi_version.restype = _i
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _i
+        _lib = L
+    return _lib
+
+
+def _call(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name}: {L.ovd_last_error().decode()}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, dtype=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError("tensor argument is None")
+    if not t.is_cuda:
+        raise ValueError("libomnihip works on device tensors only (got a CPU tensor)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _rows(t):
+    """(M, C, row stride) of a tensor whose last dim is contiguous and whose leading dims
+    collapse to one uniform row stride."""
+    if t.stride(-1) != 1:
+        raise ValueError("last dimension must be contiguous")
+    C = t.shape[-1]
+    M = t.numel() // C
+    if t.dim() == 1:
+        return 1, C, C
+    ld = t.stride(-2)
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise ValueError("leading dimensions do not collapse to a uniform row stride")
+        exp *= t.shape[d]
+    return M, C, ld
+
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def layernorm_modulate(x, out, eps, shift=None, scale=None, weight=None, bias=None, round_norm=False):
+    M, C, ldx = _rows(x)
+    Mo, Co, ldo = _rows(out)
+    if (Mo, Co) != (M, C):
+        raise ValueError("layernorm: out shape mismatch")
+    for v in (shift, scale):
+        if v is not None and (v.numel() != C or not v.is_contiguous()):
+            raise ValueError("layernorm: shift/scale must be contiguous rows of length C")
+    name = "ovd_layernorm_modulate_bf16" if out.dtype == BF16 else "ovd_layernorm_modulate_f32"
+    if out.dtype not in (BF16, F32):
+        raise TypeError("layernorm: out must be bf16 or fp32")
+    _call(name, _ptr(x, F32), ldx, _ptr(shift, F32, True), _ptr(scale, F32, True), _ptr(weight, BF16, True),
+          _ptr(bias, BF16, True), _ptr(out), ldo, M, C, float(eps), int(round_norm), _stream())
+    return out
+
+
+def rmsnorm_rope(x, weight, out, head_dim, eps, rope=None, rows_per_sample=None, tok_offset=0, n_rope=0,
+                 grid=(1, 1, 1)):
+    M, C, ldi = _rows(x)
+    Mo, Co, ldo = _rows(out)
+    if (Mo, Co) != (M, C) or (weight is not None and weight.numel() != C):
+        raise ValueError("rmsnorm: shape mismatch")
+    rope_rows = 0
+    if rope is not None:
+        if rope.dtype != F32 or rope.dim() != 4 or rope.shape[0] != 3 or rope.shape[2] != head_dim // 2 \
+                or rope.shape[3] != 2 or not rope.is_contiguous():
+            raise ValueError("rmsnorm: rope table must be contiguous fp32 [3, rows, head_dim/2, 2]")
+        rope_rows = rope.shape[1]
+    _call("ovd_rmsnorm_rope_bf16", _ptr(x, BF16), ldi, _ptr(weight, BF16, True), _ptr(rope, F32, True), rope_rows,
+          _ptr(out, BF16), ldo, M, C, head_dim, float(eps), rows_per_sample or max(M, 1), tok_offset, n_rope,
+          grid[0], grid[1], grid[2], _stream())
+    return out
+
+
+def gemm(a, w, out, bias=None, epilogue=EPI_BF16, gate=None):
+    M, K, lda = _rows(a)
+    N, Kw, ldw = _rows(w)
+    Mo, No, ldo = _rows(out)
+    if Kw != K or Mo != M or No != N:
+        raise ValueError(f"gemm: shape mismatch a[{M},{K}] w[{N},{Kw}] out[{Mo},{No}]")
+    want = BF16 if epilogue in (EPI_BF16, EPI_BF16_GELU) else F32
+    if bias is not None and (bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("gemm: bias must be a contiguous row of length N")
+    if gate is not None and (gate.numel() != N or not gate.is_contiguous()):
+        raise ValueError("gemm: gate must be a contiguous row of length N")
+    _call("ovd_gemm_bf16", _ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, BF16, True), _ptr(out, want), ldo,
+          _ptr(gate, F32, True), M, N, K, epilogue, _stream())
+    return out
+
+
+def flash_attn(q, k, v, out, k_len=None, softmax_scale=None):
+    """q [B,Lq,N,D], k/v [B,Lk,N,D], out [B,Lq,N,D] bf16; the (N,D) dims must be dense, the
+    token and batch dims may be strided (views into a fused projection buffer)."""
+    B, Lq, N, D = q.shape
+    Lk = k.shape[1]
+    for t in (q, k, v, out):
+        if t.dim() != 4 or t.stride(3) != 1 or t.stride(2) != D:
+            raise ValueError("attention: tensors must be [B,L,N,D] with dense (N,D)")
+    if k.shape != v.shape or k.shape[0] != B or k.shape[2:] != q.shape[2:] or out.shape != q.shape:
+        raise ValueError("attention: shape mismatch")
+    scale = float(softmax_scale) if softmax_scale is not None else D ** -0.5
+    _call("ovd_flash_attn_fwd_bf16", _ptr(q, BF16), _ptr(k, BF16), _ptr(v, BF16), _ptr(out, BF16), B, Lq, Lk, N, D,
+          int(Lk if k_len is None else k_len), q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+          q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream())
+    return out
+
+
+def patchify(lat, rows, patch):
+    Cin, T, H, W = lat.shape
+    if not lat.is_contiguous() or not rows.is_contiguous():
+        raise ValueError("patchify: tensors must be contiguous")
+    if lat.dtype not in (BF16, F32):
+        raise TypeError("patchify: latents must be bf16 or fp32")
+    pt, ph, pw = patch
+    n = (T // pt) * (H // ph) * (W // pw)
+    if tuple(rows.shape) != (n, Cin * pt * ph * pw):
+        raise ValueError("patchify: rows buffer has the wrong shape")
+    _call("ovd_patchify", _ptr(lat), int(lat.dtype == BF16), _ptr(rows, BF16), Cin, T, H, W, pt, ph, pw, _stream())
+    return rows
+
+
+def time_sinusoid(timesteps, out, step=0, step_ptr=None):
+    _call("ovd_time_sinusoid", _ptr(timesteps, torch.float64), _ptr(step_ptr, torch.int32, True), int(step),
+          _ptr(out, F32), out.numel(), _stream())
+    return out
+
+
+def gemv_f32(x, w, b, y, silu_in=False):
+    N, K = w.shape
+    if x.numel() != K or y.numel() != N or not (w.is_contiguous() and x.is_contiguous() and y.is_contiguous()):
+        raise ValueError("gemv: shape mismatch")
+    _call("ovd_gemv_f32", _ptr(x, F32), _ptr(w, BF16), _ptr(b, BF16, True), _ptr(y, F32), N, K, int(silu_in),
+          _stream())
+    return y
+
+
+def modulation_table(param_ptrs, e0, out):
+    n_layers, n6c = out.shape[0], out[0].numel()
+    _call("ovd_modulation_table", _ptr(param_ptrs, torch.int64), _ptr(e0, F32), _ptr(out, F32), n_layers, n6c,
+          _stream())
+    return out
+
+
+def head_modulation(mod, e, out):
+    _call("ovd_head_modulation", _ptr(mod, BF16), _ptr(e, F32), _ptr(out, F32), e.numel(), _stream())
+    return out
+
+
+def head_unpatchify(y, w, bias, out, grid, patch, out_dim):
+    M, C, ldy = _rows(y)
+    n_tok = grid[0] * grid[1] * grid[2]
+    if n_tok > M or not out.is_contiguous():
+        raise ValueError("head: activation has fewer rows than the grid has tokens")
+    _call("ovd_head_unpatchify", _ptr(y, F32), ldy, _ptr(w, BF16), _ptr(bias, BF16, True), _ptr(out, F32), n_tok, C,
+          out_dim, patch[0], patch[1], patch[2], grid[0], grid[1], grid[2], _stream())
+    return out
+
+
+def cfg_unipc_step(cond, uncond, sample, last_sample, m1, m2, coef, guide_scale, step=0, step_ptr=None):
+    n = sample.numel()
+    for t in (cond, uncond, m1, m2):
+        if t.numel() != n or not t.is_contiguous():
+            raise ValueError("cfg_unipc: buffers must be contiguous and equally sized")
+    if last_sample.dtype != sample.dtype or sample.dtype not in (BF16, F32):
+        raise TypeError("cfg_unipc: sample/last_sample must share a bf16 or fp32 dtype")
+    _call("ovd_cfg_unipc_step", _ptr(cond, F32), _ptr(uncond, F32), _ptr(sample), _ptr(last_sample), _ptr(m1, F32),
+          _ptr(m2, F32), _ptr(coef, F32), float(guide_scale), _ptr(step_ptr, torch.int32, True), int(step), n,
+          int(sample.dtype == BF16), _stream())
+
+
+def step_advance(step_ptr):
+    _call("ovd_step_advance", _ptr(step_ptr, torch.int32), _stream())

@@ -1,0 +1,222 @@
+"""Execution plan for the DiT forward on MI355X.
+
+One `DiTEngine` snapshots a WanModel's weights into the fused layouts the HIP kernels
+want (QKV as one [3C,C] matrix, cross-attention K/V as one [2C,C] matrix), owns every
+workspace buffer for a given (grid, seq_len, branches) shape, and runs the forward as a
+fixed sequence of libomnihip launches on torch's current stream: no allocation, no host
+synchronisation, so a whole sampling step can be captured into a HIP graph.
+
+Compared with the reference's eager module graph (omnivideo/modules/model.py:417-524)
+the engine
+  * evaluates the timestep MLP once per forward instead of once per token (the timestep
+    is one scalar; model.py:467-476 expands it to [B, L]);
+  * runs the conditional and unconditional branches of classifier-free guidance as one
+    batch of 2 through every token-local kernel (x2x_gen_unified.py:480-481 runs two
+    B=1 forwards);
+  * embeds the context and projects the per-layer cross-attention K/V once per video
+    (they do not depend on the latents or the timestep; model.py:170-171,480-485
+    recompute them in every layer of every forward).
+The arithmetic per element is unchanged, including the reference's bf16 rounding points.
+"""
+import math
+
+import torch
+
+from .. import _hip as H
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def build_rope_table(head_dim, rows, device, theta=10000.0):
+    """float2 (cos, sin) [3, rows, head_dim/2]: axis a (frame, height, width) fills the
+    complex pairs it owns inside a head; computed in float64 like the reference's
+    rope_params (model.py:26-34,404-411) and rounded once to fp32."""
+    c = head_dim // 2
+    parts = (c - 2 * (c // 3), c // 3, c // 3)
+    tab = torch.zeros(3, rows, c, 2, dtype=torch.float64)
+    pos = torch.arange(rows, dtype=torch.float64)
+    start = 0
+    for a, npairs in enumerate(parts):
+        dim_axis = 2 * npairs
+        freq = 1.0 / torch.pow(theta, torch.arange(0, dim_axis, 2, dtype=torch.float64) / dim_axis)
+        ang = pos[:, None] * freq[None, :]
+        tab[a, :, start:start + npairs, 0] = ang.cos()
+        tab[a, :, start:start + npairs, 1] = ang.sin()
+        start += npairs
+    return tab.to(F32).to(device).contiguous()
+
+
+class ContextCache:
+    """Embedded context and per-layer cross-attention K/V for `nb` guidance branches."""
+
+    def __init__(self, kv, text_len):
+        self.kv = kv            # [layers, nb, text_len, 2C] bf16: K (normalised) | V
+        self.text_len = text_len
+
+
+class DiTEngine:
+    def __init__(self, model, device=None):
+        """model: omnivideo.modules.model.WanModel (parameters are read, never modified)."""
+        p0 = model.patch_embedding.weight
+        self.device = torch.device(device) if device is not None else p0.device
+        if self.device.type != "cuda":
+            raise RuntimeError("DiTEngine needs the model on a HIP device; there is no CPU path")
+        self.dim, self.ffn_dim = model.dim, model.ffn_dim
+        self.num_heads, self.num_layers = model.num_heads, model.num_layers
+        self.head_dim = self.dim // self.num_heads
+        self.eps, self.freq_dim = model.eps, model.freq_dim
+        self.patch_size, self.in_dim, self.out_dim = tuple(model.patch_size), model.in_dim, model.out_dim
+        self.text_dim = model.text_dim
+        if self.head_dim != 128:
+            raise RuntimeError(f"head_dim {self.head_dim} unsupported: the attention kernel is built for 128")
+
+        def w(t):
+            return t.detach().to(self.device, BF16).contiguous()
+
+        self.w_patch = w(p0).reshape(self.dim, -1)
+        self.b_patch = w(model.patch_embedding.bias)
+        te, tm, tp = model.text_embedding, model.time_embedding, model.time_projection
+        self.w_te0, self.b_te0, self.w_te2, self.b_te2 = w(te[0].weight), w(te[0].bias), w(te[2].weight), w(te[2].bias)
+        self.w_tm0, self.b_tm0, self.w_tm2, self.b_tm2 = w(tm[0].weight), w(tm[0].bias), w(tm[2].weight), w(tm[2].bias)
+        self.w_tp, self.b_tp = w(tp[1].weight), w(tp[1].bias)
+        self.layers = []
+        mods = []
+        for blk in model.blocks:
+            sa, ca = blk.self_attn, blk.cross_attn
+            L = dict(
+                w_qkv=torch.cat([w(sa.q.weight), w(sa.k.weight), w(sa.v.weight)], 0).contiguous(),
+                b_qkv=torch.cat([w(sa.q.bias), w(sa.k.bias), w(sa.v.bias)], 0).contiguous(),
+                nq=w(sa.norm_q.weight), nk=w(sa.norm_k.weight), w_o=w(sa.o.weight), b_o=w(sa.o.bias),
+                n3w=w(blk.norm3.weight), n3b=w(blk.norm3.bias),
+                w_cq=w(ca.q.weight), b_cq=w(ca.q.bias), cnq=w(ca.norm_q.weight), cnk=w(ca.norm_k.weight),
+                w_ckv=torch.cat([w(ca.k.weight), w(ca.v.weight)], 0).contiguous(),
+                b_ckv=torch.cat([w(ca.k.bias), w(ca.v.bias)], 0).contiguous(),
+                w_co=w(ca.o.weight), b_co=w(ca.o.bias),
+                w_f0=w(blk.ffn[0].weight), b_f0=w(blk.ffn[0].bias), w_f2=w(blk.ffn[2].weight), b_f2=w(blk.ffn[2].bias),
+                mod=w(blk.modulation).reshape(6, self.dim))
+            self.layers.append(L)
+            mods.append(L["mod"].data_ptr())
+        self.mod_ptrs = torch.tensor(mods, dtype=torch.int64, device=self.device)
+        self.w_head, self.b_head = w(model.head.head.weight), w(model.head.head.bias)
+        self.head_mod = w(model.head.modulation).reshape(2, self.dim)
+        self._shape = None
+        self.timing = None
+
+    # ------------------------------------------------------------------ workspaces
+    def plan(self, grid, seq_len, nb):
+        key = (tuple(grid), int(seq_len), int(nb))
+        if self._shape == key:
+            return
+        dev, C, F = self.device, self.dim, self.ffn_dim
+        M = nb * seq_len
+        n_tok = grid[0] * grid[1] * grid[2]
+        if n_tok > seq_len:
+            raise ValueError(f"seq_len {seq_len} shorter than the {n_tok} latent tokens")
+        kpatch = self.in_dim * math.prod(self.patch_size)
+        e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+        self.x = e(nb, seq_len, C, dt=F32)
+        self.h = e(M, C)
+        self.qkv = e(nb, seq_len, 3 * C)
+        self.att = e(nb, seq_len, C)
+        self.ffn = e(M, F)
+        self.y = e(M, C, dt=F32)
+        self.rows = e(n_tok, kpatch)
+        self.sin = e(self.freq_dim, dt=F32)
+        self.e_tmp, self.e_vec = e(C, dt=F32), e(C, dt=F32)
+        self.e0 = e(6 * C, dt=F32)
+        self.mod = e(self.num_layers, 6, C, dt=F32)
+        self.hmod = e(2, C, dt=F32)
+        self.rope = build_rope_table(self.head_dim, max(grid), dev)
+        self.grid, self.seq_len, self.nb, self.n_tok = tuple(grid), seq_len, nb, n_tok
+        self._shape = key
+
+    # ------------------------------------------------------------------ context (once per video)
+    def encode_context(self, contexts, text_len):
+        """contexts: list (one per guidance branch) of [n_i, text_dim] tensors, n_i <= text_len.
+        Zero-pads to text_len, runs text_embedding (model.py:480-485) and every layer's
+        cross-attention K projection + RMSNorm and V projection (model.py:170-171)."""
+        nb, C, dev = len(contexts), self.dim, self.device
+        pad = torch.zeros(nb, text_len, self.text_dim, dtype=BF16, device=dev)
+        for i, c in enumerate(contexts):
+            c = c.reshape(-1, self.text_dim)
+            if c.shape[0] > text_len:
+                raise ValueError(f"context of {c.shape[0]} rows exceeds text_len {text_len}")
+            pad[i, :c.shape[0]] = c.to(dev, BF16)
+        hid = torch.empty(nb * text_len, C, dtype=BF16, device=dev)
+        emb = torch.empty(nb * text_len, C, dtype=BF16, device=dev)
+        H.gemm(pad.view(nb * text_len, -1), self.w_te0, hid, self.b_te0, H.EPI_BF16_GELU)
+        H.gemm(hid, self.w_te2, emb, self.b_te2, H.EPI_BF16)
+        kv = torch.empty(self.num_layers, nb, text_len, 2 * C, dtype=BF16, device=dev)
+        for l, L in enumerate(self.layers):
+            flat = kv[l].view(nb * text_len, 2 * C)
+            H.gemm(emb, L["w_ckv"], flat, L["b_ckv"], H.EPI_BF16)
+            kview = flat[:, :C]
+            H.rmsnorm_rope(kview, L["cnk"], kview, self.head_dim, self.eps)
+        return ContextCache(kv, text_len)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, lat, timesteps, ctx, out, step=0, step_ptr=None, tok_offset=0):
+        """lat [Cin,T,H,W] (bf16 or fp32, rounded to bf16 on entry as the reference's bf16
+        latents are), timesteps int64 device table, ctx a ContextCache for self.nb branches,
+        out fp32 [nb, Cout, T, H, W].  plan() must have been called for this shape."""
+        C, N, D, nb, S = self.dim, self.num_heads, self.head_dim, self.nb, self.seq_len
+        M = nb * S
+        gf, gh, gw = self.grid
+        n_tok = self.n_tok
+        if ctx.kv.shape[1] != nb:
+            raise ValueError("context cache was built for a different number of branches")
+        # patch embedding (model.py:455-464): rows beyond the real tokens stay zero
+        H.patchify(lat, self.rows, self.patch_size)
+        self.x.zero_()
+        H.gemm(self.rows, self.w_patch, self.x[0, :n_tok], self.b_patch, H.EPI_F32)
+        for b in range(1, nb):
+            self.x[b].copy_(self.x[0])
+        # timestep embedding, once (model.py:467-476)
+        H.time_sinusoid(timesteps, self.sin, step, step_ptr)
+        H.gemv_f32(self.sin, self.w_tm0, self.b_tm0, self.e_tmp)
+        H.gemv_f32(self.e_tmp, self.w_tm2, self.b_tm2, self.e_vec, silu_in=True)
+        H.gemv_f32(self.e_vec, self.w_tp, self.b_tp, self.e0, silu_in=True)
+        H.modulation_table(self.mod_ptrs, self.e0, self.mod)
+        x2 = self.x.view(M, C)
+        qkv2 = self.qkv.view(M, 3 * C)
+        q4 = self.qkv[:, :, :C].unflatten(2, (N, D))
+        k4 = self.qkv[:, :, C:2 * C].unflatten(2, (N, D))
+        v4 = self.qkv[:, :, 2 * C:].unflatten(2, (N, D))
+        att4 = self.att.unflatten(2, (N, D))
+        att2 = self.att.view(M, C)
+        for l, L in enumerate(self.layers):
+            mod = self.mod[l]
+            # self-attention (model.py:242-246)
+            H.layernorm_modulate(x2, self.h, self.eps, shift=mod[0], scale=mod[1], round_norm=(l == 0))
+            H.gemm(self.h, L["w_qkv"], qkv2, L["b_qkv"], H.EPI_BF16)
+            for sl, nw in ((slice(0, C), L["nq"]), (slice(C, 2 * C), L["nk"])):
+                v_ = qkv2[:, sl]
+                H.rmsnorm_rope(v_, nw, v_, D, self.eps, rope=self.rope, rows_per_sample=S, tok_offset=tok_offset,
+                               n_rope=n_tok, grid=self.grid)
+            if self.timing is not None:      # profiling hook: events around the dominant kernel
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            H.flash_attn(q4, k4, v4, att4, k_len=n_tok)
+            if self.timing is not None:
+                ev[1].record()
+                self.timing.append(ev)
+            H.gemm(att2, L["w_o"], x2, L["b_o"], H.EPI_RESID, gate=mod[2])
+            # cross-attention (model.py:250)
+            H.layernorm_modulate(x2, self.h, self.eps, weight=L["n3w"], bias=L["n3b"])
+            qc = qkv2[:, :C]
+            H.gemm(self.h, L["w_cq"], qc, L["b_cq"], H.EPI_BF16)
+            H.rmsnorm_rope(qc, L["cnq"], qc, D, self.eps)
+            kvl = ctx.kv[l]
+            H.flash_attn(q4, kvl[:, :, :C].unflatten(2, (N, D)), kvl[:, :, C:].unflatten(2, (N, D)), att4)
+            H.gemm(att2, L["w_co"], x2, L["b_co"], H.EPI_RESID)
+            # feed-forward (model.py:251-254)
+            H.layernorm_modulate(x2, self.h, self.eps, shift=mod[3], scale=mod[4])
+            H.gemm(self.h, L["w_f0"], self.ffn, L["b_f0"], H.EPI_BF16_GELU)
+            H.gemm(self.ffn, L["w_f2"], x2, L["b_f2"], H.EPI_RESID, gate=mod[5])
+        # head + unpatchify (model.py:520-524)
+        H.head_modulation(self.head_mod, self.e_vec, self.hmod)
+        H.layernorm_modulate(x2, self.y, self.eps, shift=self.hmod[0], scale=self.hmod[1])
+        for b in range(nb):
+            H.head_unpatchify(self.y[b * S:(b + 1) * S], self.w_head, self.b_head, out[b], self.grid,
+                              self.patch_size, self.out_dim)
+        return out

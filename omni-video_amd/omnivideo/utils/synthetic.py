@@ -39,8 +39,8 @@ def dit_config(name="1.3B", **over):
     elif name == "A14B":
         base.update(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40)
     elif name == "tiny":
-        base.update(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=128,
-                    vlm_in_dim=96, text_len=48)
+        base.update(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=256,
+                    vlm_in_dim=256, text_len=48)
     else:
         raise ValueError(name)
     base.update(over)

@@ -1,0 +1,260 @@
+"""Sampling pipeline with the reference's entry point (reference:
+omnivideo/x2x_gen_unified.py: OmniVideoX2XUnified.__init__ :26-44, .generate :261-278).
+
+What changes underneath, with unchanged arithmetic per element:
+  * both guidance branches run as one batch of 2 through a DiTEngine (engine.py), with
+    the mixed context assembled, embedded and projected to per-layer cross-attention
+    K/V once per video instead of once per layer per forward per step;
+  * guidance combine + UniPC update is one fused launch per step;
+  * a whole step (2 forwards + update) is captured once per expert into a HIP graph and
+    replayed; the step index lives on the device, so the loop has no host
+    synchronisation (the reference syncs on `t.item()` every step, :235);
+  * both experts stay resident in HBM (288 GB): no CPU offload round trips.
+Out of the accelerated path and therefore not provided here: the umT5 text encoder and
+FSDP sharding.  Text conditions come in as tensors (`precomputed_context`, and
+`precomputed_context_null` for the negative prompt), or through a user-supplied
+`self.text_encoder` callable with the reference's `(texts, device) -> list[Tensor]`
+convention.
+"""
+import logging
+import math
+import os
+import random
+import sys
+
+import torch
+import torch.distributed as dist
+
+from . import _hip as H
+from .modules.unified_model import UnifiedWanWithMixedConditionModel
+from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class DenoiseLoop:
+    """The body of the reference's `for t in timesteps` loop (x2x_gen_unified.py:474-492)
+    for one latent, as graph-replayable device work."""
+
+    def __init__(self, models_by_step, lat, ctx_pairs, seq_len, scheduler, guide_scale, use_graph=True,
+                 tok_offset=0):
+        """models_by_step: list (one per step) of the UnifiedWan model serving that step;
+        ctx_pairs: {id(model): (mixed_cond, mixed_uncond)} context tensors [n, text_dim]."""
+        self.lat = lat
+        self.sched = scheduler
+        self.guide = float(guide_scale)
+        self.use_graph = use_graph
+        self.models_by_step = models_by_step
+        dev = lat.device
+        wm0 = models_by_step[0].wan_model
+        pt, ph, pw = wm0.patch_size
+        self.grid = (lat.shape[1] // pt, lat.shape[2] // ph, lat.shape[3] // pw)
+        self.out = torch.empty(2, wm0.out_dim, *lat.shape[1:], dtype=F32, device=dev)
+        self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.state = scheduler.prepare(lat)
+        self.done = 0
+        self.engines, self.caches, self.graphs = {}, {}, {}
+        for m in models_by_step:
+            if id(m) in self.engines:
+                continue
+            eng = m.wan_model.engine()
+            eng.plan(self.grid, seq_len, 2)
+            self.engines[id(m)] = eng
+            self.caches[id(m)] = eng.encode_context(list(ctx_pairs[id(m)]), m.wan_model.text_len)
+
+    def _step(self, key):
+        eng = self.engines[key]
+        eng.forward(self.lat, self.state["tsteps"], self.caches[key], self.out, step_ptr=self.step_ptr)
+        self.sched.step_cfg(self.out[0], self.out[1], self.guide, self.lat, step_ptr=self.step_ptr)
+        H.step_advance(self.step_ptr)
+
+    def step_once(self, i):
+        key = id(self.models_by_step[i])
+        if not self.use_graph:
+            self._step(key)
+        elif key in self.graphs:
+            self.graphs[key].replay()
+        else:
+            # one eager step warms every lazy initialisation, then the same launch sequence
+            # is captured (capture records, it does not execute) and replayed from then on
+            self._step(key)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                self._step(key)
+            self.graphs[key] = g
+
+    def run(self, num_steps=None):
+        """Runs the next `num_steps` steps (default: all that remain)."""
+        end = len(self.models_by_step) if num_steps is None else self.done + num_steps
+        while self.done < end:
+            self.step_once(self.done)
+            self.done += 1
+        return self.lat
+
+
+class OmniVideoX2XUnified:
+
+    def __init__(self, config, checkpoint_dir, vlm_in_dim=4096, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False,
+                 use_usp=False, sp_size=None, t5_cpu=False, use_visual_context_adapter=False,
+                 visual_context_adapter_patch_size=(1, 4, 4), max_context_len=None, init_on_cpu=True,
+                 wan_config=None, fsdp_shard_size=None):
+        self.device = torch.device(f"cuda:{device_id}")
+        self.config, self.rank, self.t5_cpu, self.dit_fsdp, self.init_on_cpu = config, rank, t5_cpu, dit_fsdp, init_on_cpu
+        if dit_fsdp or t5_fsdp:
+            raise NotImplementedError("FSDP sharding is not part of this build: both experts fit one MI355X")
+        self.num_train_timesteps = config.num_train_timesteps
+        self.boundary = config.get("boundary", 0.875)
+        self.param_dtype = config.param_dtype
+        self.vae_stride, self.patch_size = config.vae_stride, config.patch_size
+        self.text_encoder = None        # see module docstring
+        self.vae = self._build_vae(os.path.join(checkpoint_dir, config.vae_checkpoint) if checkpoint_dir else None)
+        self._init_sequence_parallel(use_usp, sp_size)
+        self._build_models(wan_config, checkpoint_dir, vlm_in_dim, use_visual_context_adapter,
+                           visual_context_adapter_patch_size, max_context_len)
+        self.sample_neg_prompt = config.sample_neg_prompt_en
+        self.special_tokens = self._load_special_tokens(checkpoint_dir)
+        self.use_graph = True
+
+    # ------------------------------------------------------------------ construction helpers
+    def _build_vae(self, vae_pth):
+        try:
+            from .modules.vae2_1 import Wan2_1_VAE
+        except ImportError:
+            return None
+        if vae_pth is None or not os.path.exists(vae_pth):
+            logging.info("no VAE checkpoint found: generate() will return latents unless self.vae is set")
+            return None
+        return Wan2_1_VAE(vae_pth=vae_pth, device=self.device)
+
+    def _init_sequence_parallel(self, use_usp, sp_size):
+        self.use_usp = use_usp
+        if use_usp:
+            from .distributed.util import get_rank, get_sequence_parallel_size, init_sequence_parallel_group
+            self.sp_group = init_sequence_parallel_group(self.config.get("sp_size", 1) if sp_size is None else sp_size)
+            self.sp_size = get_sequence_parallel_size()
+            self.sp_rank = get_rank(self.sp_group)
+        else:
+            self.sp_group, self.sp_size, self.sp_rank = None, 1, 0
+
+    def _new_model(self, wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len):
+        if wan_config is None:
+            raise NotImplementedError(
+                "construct with wan_config=... and load_state_dict() the released checkpoint, as the reference "
+                "CLI does (tools/inference/generate_omni_v2v.py:495-557); diffusers-format directories are not read")
+        m = UnifiedWanWithMixedConditionModel(
+            wan_config=wan_config, vlm_in_dim=vlm_in_dim, precision_dtype=self.param_dtype,
+            use_usp=self.use_usp, use_visual_context_adapter=use_vca,
+            visual_context_adapter_patch_size=vca_patch, max_context_len=max_context_len, skip_init=True)
+        return m.to(self.param_dtype).to(self.device).eval()
+
+    def _build_models(self, wan_config, checkpoint_dir, vlm_in_dim, use_vca, vca_patch, max_context_len):
+        self.high_noise_model = self._new_model(wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len)
+        self.low_noise_model = self._new_model(wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len)
+
+    def _load_special_tokens(self, checkpoint_dir):
+        path = os.path.join(checkpoint_dir, "special_tokens.pkl") if checkpoint_dir else None
+        if not path or not os.path.exists(path):
+            return None
+        toks = torch.load(path, map_location="cpu", weights_only=True)
+        assert isinstance(toks, dict), "special_tokens should be a dictionary"
+        return {k: v.to(self.param_dtype).to(self.device) for k, v in toks.items()}
+
+    def _prepare_model_for_timestep(self, t, boundary, offload_model=False):
+        """reference :228-258 without the offload traffic: both experts stay on the device."""
+        return self.high_noise_model if float(t) >= boundary else self.low_noise_model
+
+    # ------------------------------------------------------------------ generate
+    def generate(self, input_prompt, precomputed_context=None, ar_vision_input=None, visual_emb=None,
+                 size=(1280, 720), frame_num=81, shift=5.0, sample_solver="unipc", sampling_steps=50,
+                 guide_scale=5.0, n_prompt="", seed=-1, precision_dtype=torch.bfloat16, offload_model=True,
+                 classifier_free_ratio=0.0, unconditioned_context=None, condition_mode="auto",
+                 precomputed_context_null=None, noise=None, return_latents=False):
+        """reference :261-540.  Extra keyword-only extensions: `precomputed_context_null`
+        (negative-prompt embedding when no text encoder is attached), `noise` (use these
+        initial latents instead of drawing them on the device), `return_latents`."""
+        if precision_dtype != torch.bfloat16:
+            raise NotImplementedError("the HIP path computes in bf16 (the reference's GPU setting)")
+        if sample_solver != "unipc":
+            raise NotImplementedError("Unsupported solver." if sample_solver != "dpm++"
+                                      else "dpm++ is not built yet; use unipc (the default)")
+        if condition_mode not in ("auto", "full"):
+            raise NotImplementedError("only condition_mode 'auto'/'full' reaches the DiT in the reference")
+        F_ = frame_num
+        z_dim = self.high_noise_model.wan_model.in_dim
+        target_shape = (z_dim, (F_ - 1) // self.vae_stride[0] + 1, size[1] // self.vae_stride[1],
+                        size[0] // self.vae_stride[2])
+        seq_len = math.ceil((target_shape[2] * target_shape[3]) / (self.patch_size[1] * self.patch_size[2]) *
+                            target_shape[1] / self.sp_size) * self.sp_size
+        if n_prompt == "":
+            n_prompt = self.sample_neg_prompt
+        seed = seed if seed >= 0 else random.randint(0, sys.maxsize)
+        seed_g = torch.Generator(device=self.device)
+        seed_g.manual_seed(seed)
+
+        def to2d(x):
+            if x is None:
+                return None
+            if isinstance(x, list) and len(x) == 1:
+                x = x[0]
+            if not isinstance(x, torch.Tensor):
+                x = torch.tensor(x)
+            if x.dim() == 3 and x.size(0) == 1:
+                x = x.squeeze(0)
+            return x
+
+        if precomputed_context is not None:
+            context = [to2d(precomputed_context).to(self.device, dtype=precision_dtype)]
+        elif self.text_encoder is not None:
+            context = [t.to(self.device) for t in self.text_encoder([input_prompt], self.device)]
+        else:
+            raise ValueError("no text encoder attached: pass precomputed_context")
+        if precomputed_context_null is not None:
+            context_null = [to2d(precomputed_context_null).to(self.device, dtype=precision_dtype)]
+        elif self.text_encoder is not None:
+            context_null = [t.to(self.device) for t in self.text_encoder([n_prompt], self.device)]
+        else:
+            raise ValueError("no text encoder attached: pass precomputed_context_null for the negative prompt")
+        if self.use_usp and dist.is_initialized() and self.sp_size > 1:
+            src = self.rank - self.sp_rank
+            for ctx in (context, context_null):
+                for i in range(len(ctx)):
+                    dist.broadcast(ctx[i], src=src, group=self.sp_group)
+
+        if noise is None:
+            noise = torch.randn(*target_shape, dtype=precision_dtype, device=self.device, generator=seed_g)
+        lat = noise.to(self.device, precision_dtype).contiguous().clone()
+        assert tuple(lat.shape) == tuple(target_shape)
+
+        with torch.no_grad():
+            boundary = self.boundary * self.num_train_timesteps
+            sched = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                                use_dynamic_shifting=False)
+            sched.set_timesteps(sampling_steps, device="cpu", shift=shift)
+            # null AR vision: two rows of 1e-6 (reference :433-449)
+            ar_null = None
+            if ar_vision_input is not None:
+                vlm_dim = ar_vision_input[0].size(-1) if isinstance(ar_vision_input, list) else ar_vision_input.size(-1)
+                if isinstance(unconditioned_context, dict) and "uncond_ar_vision" in unconditioned_context:
+                    unc = unconditioned_context["uncond_ar_vision"]
+                else:
+                    unc = torch.zeros(2, vlm_dim, device=self.device, dtype=precision_dtype) + 1e-6
+                ar_null = [unc for _ in ar_vision_input] if isinstance(ar_vision_input, list) else unc
+            models = [self._prepare_model_for_timestep(t, boundary) for t in sched.timesteps.tolist()]
+            pairs = {}
+            for m in models:
+                if id(m) not in pairs:
+                    c = m.build_mixed_context(1, context, ar_vision_input, visual_emb, self.special_tokens)[0]
+                    u = m.build_mixed_context(1, context_null, ar_null, visual_emb, self.special_tokens)[0]
+                    pairs[id(m)] = (c, u)
+            loop = DenoiseLoop(models, lat, pairs, seq_len, sched, guide_scale, use_graph=self.use_graph)
+            lat = loop.run()
+            if dist.is_initialized():
+                dist.barrier()
+            is_decode_rank = (self.sp_rank == 0) if self.use_usp else (self.rank == 0)
+            if return_latents or self.vae is None:
+                return lat if is_decode_rank else None
+            videos = self.vae.decode([lat]) if is_decode_rank else [None]
+        if dist.is_initialized():
+            dist.barrier()
+        return videos[0] if is_decode_rank else None

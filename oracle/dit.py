@@ -118,11 +118,17 @@ def attention(q, k, v, k_len=None, flow="fp32"):
     half precision: attention.py:59-83)."""
     q, k, v = rb(q, flow), rb(k, flow), rb(v, flow)
     D = q.shape[-1]
-    s = torch.einsum("qnd,knd->nqk", q, k) / math.sqrt(D)
     if k_len is not None and k_len < k.shape[0]:
-        s[:, :, k_len:] = float("-inf")
-    p = torch.softmax(s, dim=-1)
-    return rb(torch.einsum("nqk,knd->qnd", p, v), flow)
+        k, v = k[:k_len], v[:k_len]          # masked keys get zero weight: same as dropping them
+    out = torch.empty(q.shape[0], q.shape[1], v.shape[-1])
+    kt = k.permute(1, 2, 0)                   # [N, D, Lk]
+    vt = v.permute(1, 0, 2)                   # [N, Lk, D]
+    qchunk = max(1, (1 << 27) // max(1, k.shape[0] * q.shape[1]))   # bound the score block to ~0.5 GB
+    for q0 in range(0, q.shape[0], qchunk):
+        s = torch.matmul(q[q0:q0 + qchunk].permute(1, 0, 2), kt) / math.sqrt(D)
+        p = torch.softmax(s, dim=-1)
+        out[q0:q0 + qchunk] = torch.matmul(p, vt).permute(1, 0, 2)
+    return rb(out, flow)
 
 
 def self_attention(h, sd, pre, num_heads, eps, angles, n_valid, flow):

@@ -1,0 +1,165 @@
+"""Block- and model-level parity of the HIP path behind the reference's module surface.
+
+Two comparisons per case:
+  * against the oracle's bf16 flow (same rounding points, bf16-rounded weights): the
+    tight check, tolerance = accumulated bf16 rounding noise;
+  * against the committed fp32 golden of the reference itself (tests/golden/dit_tiny.npz):
+    the end-to-end bf16-vs-fp32 tolerance (relative L2 < 3e-2).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from omnivideo.utils import synthetic as syn
+from oracle import dit as O
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "dit_tiny.npz")).items()}
+
+
+@pytest.fixture(scope="module")
+def W():
+    cfg = syn.dit_config("tiny")
+    sd = syn.make_unified_state_dict(cfg, 0)
+    return cfg, sd, O.round_weights_bf16(sd), syn.make_special_tokens(cfg, 0)
+
+
+def build_unified(cfg, sd, max_context_len=None):
+    from omnivideo.modules.unified_model import UnifiedWanWithMixedConditionModel
+    m = UnifiedWanWithMixedConditionModel(
+        wan_config=dict(cfg), vlm_in_dim=cfg["vlm_in_dim"], use_visual_context_adapter=True,
+        visual_context_adapter_patch_size=cfg["visual_patch_size"],
+        max_context_len=cfg["text_len"] if max_context_len is None else max_context_len, eps=cfg["eps"],
+        skip_init=True)
+    m.load_state_dict(sd, strict=True)
+    return m.to(BF16).cuda().eval()
+
+
+def inputs(cfg, seed=1):
+    return dict(lat=syn.randn("in.lat", (16, 3, 8, 12), seed),
+                text=syn.randn("in.text", (10, cfg["text_dim"]), seed),
+                text_null=syn.randn("in.text_null", (6, cfg["text_dim"]), seed),
+                ar=syn.randn("in.ar", (1, 7, cfg["vlm_in_dim"]), seed),
+                visual=syn.randn("in.visual", (1, 16, 3, 8, 12), seed))
+
+
+def test_state_dict_names_match_reference_layout(W):
+    cfg, sd, _, _ = W
+    m = build_unified(cfg, sd)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+
+
+def test_self_and_cross_attention_modules(W, G):
+    cfg, sd, sdb, _ = W
+    m = build_unified(cfg, sd).wan_model
+    blk = m.blocks[1]
+    x = syn.randn("probe.x", (1, 80, 256), 3)
+    grid = torch.tensor([[3, 4, 6]])
+    y = blk.self_attn(x.cuda().to(BF16), torch.tensor([72]), grid, None)
+    ref = O.self_attention(O.rb(x[0], "bf16"), sdb, "wan_model.blocks.1.self_attn", 2, cfg["eps"],
+                           O.rope_angles(128, (3, 4, 6)), 72, "bf16")
+    assert rel_l2(y[0], ref) < 1.5e-2
+    assert rel_l2(y[0], G["self_attn"]) < 3e-2
+    c = syn.randn("probe.ctx", (1, 48, 256), 3)
+    y = blk.cross_attn(x.cuda().to(BF16), c.cuda().to(BF16), None)
+    kv = O.cross_kv(O.rb(c[0], "bf16"), sdb, "wan_model.blocks.1.cross_attn", cfg["eps"], "bf16")
+    ref = O.cross_attention(O.rb(x[0], "bf16"), kv, sdb, "wan_model.blocks.1.cross_attn", 2, cfg["eps"], "bf16")
+    assert rel_l2(y[0], ref) < 1.5e-2
+    assert rel_l2(y[0], G["cross_attn"]) < 3e-2
+
+
+def test_attention_block_module(W, G):
+    cfg, sd, sdb, _ = W
+    blk = build_unified(cfg, sd).wan_model.blocks[1]
+    x = syn.randn("probe.x", (1, 80, 256), 3)
+    c = syn.randn("probe.ctx", (1, 48, 256), 3)
+    e0 = syn.randn("probe.e0", (1, 1, 6, 256), 3, 0.3)
+    y = blk(x.cuda(), e0.cuda(), torch.tensor([72]), torch.tensor([[3, 4, 6]]), None, c.cuda().to(BF16), None)
+    kv = O.cross_kv(O.rb(c[0], "bf16"), sdb, "wan_model.blocks.1.cross_attn", cfg["eps"], "bf16")
+    ref = O.block_forward(x[0], e0[0, 0], kv, sdb, "wan_model.blocks.1", cfg, O.rope_angles(128, (3, 4, 6)), 72,
+                          "bf16")
+    assert y.dtype == F32
+    assert rel_l2(y[0], ref) < 1e-2
+    assert rel_l2(y[0], G["block"]) < 2e-2
+
+
+def test_condition_pieces(W, G):
+    cfg, sd, sdb, _ = W
+    m = build_unified(cfg, sd)
+    inp = inputs(cfg)
+    v = m.visual_context_adapter(inp["visual"].cuda())
+    assert v.dtype == F32 and tuple(v.shape) == (1, 18, cfg["text_dim"])
+    assert rel_l2(v[0], O.visual_adapter(inp["visual"][0], sdb, cfg, "bf16")) < 1e-2
+    assert rel_l2(v[0], G["visual_adapter"]) < 2e-2
+    p = m._project_vlm(inp["ar"][0].cuda())
+    assert rel_l2(p, O.vlm_project(inp["ar"][0], sdb, cfg, "bf16")) < 1e-2
+    assert rel_l2(p, G["vlm_proj"]) < 2e-2
+
+
+CASES = {
+    "text_only": dict(t=731, seq_len=72, text="text"),
+    "full_special_pad": dict(t=999, seq_len=80, text="text", ar="ar", visual=True, special=True),
+    "null_branch": dict(t=208, seq_len=72, text="text_null", ar="null", visual=True, special=True),
+    "truncated_ctx30": dict(t=500, seq_len=72, text="text", ar="ar", visual=True, special=True, max_ctx=30),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_unified_forward(W, G, name):
+    cfg, sd, sdb, sp = W
+    case = CASES[name]
+    inp = inputs(cfg)
+    m = build_unified(cfg, sd, case.get("max_ctx"))
+    ar = None
+    if case.get("ar") == "ar":
+        ar = inp["ar"]
+    elif case.get("ar") == "null":
+        ar = torch.zeros(2, cfg["vlm_in_dim"]) + 1e-6
+    special = {k: v.cuda().to(BF16) for k, v in sp.items()} if case.get("special") else None
+    lat = inp["lat"].to(BF16)
+    kw = dict(context=[inp[case["text"]].cuda().to(BF16)], seq_len=case["seq_len"], special_token_dict=special)
+    if ar is not None:
+        kw["ar_vision_input"] = [ar.reshape(-1, ar.shape[-1]).cuda().to(BF16)]
+    if case.get("visual"):
+        kw["visual_emb"] = inp["visual"].cuda()
+    out = m([lat.cuda()], t=torch.tensor([case["t"]]), **kw)[0]
+    assert out.dtype == F32 and tuple(out.shape) == (16, 3, 8, 12)
+    cfg_o = dict(cfg, text_len=case.get("max_ctx", cfg["text_len"]))
+    ref = O.unified_forward(lat.float(), case["t"], sdb, cfg_o, case["seq_len"], "bf16", text=inp[case["text"]],
+                            ar_vision=ar, visual=inp["visual"] if case.get("visual") else None,
+                            special=sp if case.get("special") else None)
+    assert rel_l2(out, ref) < 1.5e-2, rel_l2(out, ref)
+    assert rel_l2(out, G[name]) < 3e-2, rel_l2(out, G[name])
+    # second call hits the context cache and must reproduce the result exactly
+    out2 = m([lat.cuda()], t=torch.tensor([case["t"]]), **kw)[0]
+    assert torch.equal(out, out2)
+
+
+def test_engine_cfg_batch_matches_single_branch(W):
+    """Running cond + uncond as one batch of 2 gives bitwise the two B=1 results."""
+    cfg, sd, _, _ = W
+    m = build_unified(cfg, sd).wan_model
+    inp = inputs(cfg)
+    lat = inp["lat"].cuda().to(BF16)
+    c1, c2 = inp["text"].cuda().to(BF16), inp["text_null"].cuda().to(BF16)
+    t = torch.tensor([650])
+    a = m([lat], t, [c1], 80)[0].clone()
+    b = m([lat], t, [c2], 80)[0].clone()
+    eng = m.engine()
+    eng.plan((3, 4, 6), 80, 2)
+    cache = eng.encode_context([c1, c2], m.text_len)
+    out = torch.empty(2, 16, 3, 8, 12, device="cuda")
+    eng.forward(lat, t.to("cuda", torch.float64), cache, out)
+    assert torch.equal(out[0], a) and torch.equal(out[1], b)

@@ -1,0 +1,264 @@
+"""Per-kernel parity: every libomnihip entry point (called through the C-ABI binding)
+against the CPU oracle on the same seeded inputs.  Tolerances are stated per test:
+bf16 outputs are compared at one-to-two bf16 ulps (2^-8 relative), fp32 paths at 1e-5."""
+import math
+
+import pytest
+import torch
+
+from omnivideo.utils import synthetic as syn
+from oracle import dit as O
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def H():
+    import omnivideo._hip as H
+    assert torch.cuda.is_available()
+    H.lib()
+    return H
+
+
+def dev(t, dt=None):
+    t = t.cuda()
+    return t.to(dt) if dt is not None else t
+
+
+def rb(x):
+    return x.to(BF16).to(F32)
+
+
+def assert_bf16_close(got, want, ulps=2.0, atol=1e-3, flip_frac=0.0, flip_atol=0.0):
+    """|got-want| <= atol + ulps*2^-8*|want| everywhere, except that a fraction flip_frac of
+    the elements may be off by up to flip_atol more: an intermediate bf16 rounding that
+    lands on the other side of a tie when the fp32 input differs in its last bit."""
+    got, want = got.float().cpu(), want.float().cpu()
+    err = (got - want).abs()
+    tol = atol + ulps * 2.0 ** -8 * want.abs()
+    bad = err > tol
+    assert not (err > tol + flip_atol).any(), f"max err {err.max():.4g}"
+    assert bad.sum() <= flip_frac * bad.numel(), f"{int(bad.sum())}/{bad.numel()} off; max err {err.max():.4g}"
+
+
+@pytest.mark.parametrize("C,M", [(256, 7), (1536, 33), (5120, 5), (4096, 9)])
+def test_layernorm_modulate(H, C, M):
+    x = syn.randn("ln.x", (M, C), 1, 3.0) + 0.5
+    sh, sc = syn.randn("ln.sh", (C,), 1, 0.3), syn.randn("ln.sc", (C,), 1, 0.3)
+    w, b = rb(1 + syn.randn("ln.w", (C,), 1, 0.1)), rb(syn.randn("ln.b", (C,), 1, 0.1))
+    # plain + modulation, fp32 out
+    out = torch.empty(M, C, device="cuda")
+    H.layernorm_modulate(dev(x), out, 1e-6, shift=dev(sh), scale=dev(sc))
+    ref = O.layer_norm(x, 1e-6) * (1 + sc) + sh
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+    # affine, bf16 out
+    outb = torch.empty(M, C, device="cuda", dtype=BF16)
+    H.layernorm_modulate(dev(x), outb, 1e-6, weight=dev(w, BF16), bias=dev(b, BF16))
+    assert_bf16_close(outb, O.layer_norm(x, 1e-6, w, b), ulps=1.01, atol=1e-6)
+    # block-0 rounding
+    H.layernorm_modulate(dev(x), outb, 1e-6, shift=dev(sh), scale=dev(sc), round_norm=True)
+    assert_bf16_close(outb, rb(O.layer_norm(x, 1e-6)) * (1 + sc) + sh, ulps=1.01, atol=1e-6, flip_frac=1e-3,
+                      flip_atol=0.04)
+
+
+def test_layernorm_rejects_bad_width(H):
+    with pytest.raises(RuntimeError, match="multiple of 256"):
+        H.layernorm_modulate(torch.zeros(4, 100, device="cuda"), torch.zeros(4, 100, device="cuda"), 1e-6)
+
+
+@pytest.mark.parametrize("C,N,grid,L", [(256, 2, (3, 4, 6), 80), (1536, 12, (2, 5, 7), 70), (5120, 40, (1, 3, 4), 12)])
+def test_rmsnorm_rope(H, C, N, grid, L):
+    from omnivideo.modules.engine import build_rope_table
+    D = C // N
+    x = rb(syn.randn("rr.x", (L, C), 2, 2.0))
+    w = rb(1 + syn.randn("rr.w", (C,), 2, 0.1))
+    n_tok = grid[0] * grid[1] * grid[2]
+    out = torch.empty(L, C, device="cuda", dtype=BF16)
+    H.rmsnorm_rope(dev(x, BF16), dev(w, BF16), out, D, 1e-6, rope=build_rope_table(D, max(grid), "cuda"),
+                   rows_per_sample=L, n_rope=n_tok, grid=grid)
+    ref = O.rope_rotate(O.rms_norm(x, w, 1e-6, "bf16").view(L, N, D), O.rope_angles(D, grid)).reshape(L, C)
+    # the kernel's fp32 1/rms can differ from the CPU's in the last bit (summation order),
+    # which occasionally flips one of the two intermediate bf16 roundings
+    assert_bf16_close(out, rb(ref), ulps=1.01, atol=1e-6, flip_frac=2e-3, flip_atol=0.04)
+    # no rope (cross-attention q/k, VLM norm)
+    H.rmsnorm_rope(dev(x, BF16), dev(w, BF16), out, D, 1e-6)
+    assert_bf16_close(out, O.rms_norm(x, w, 1e-6, "bf16"), ulps=1.01, atol=1e-6, flip_frac=2e-3, flip_atol=0.04)
+
+
+def test_rmsnorm_rope_batched_and_offset(H):
+    """Two samples stacked (CFG batch) and a token offset (sequence-parallel shard)."""
+    from omnivideo.modules.engine import build_rope_table
+    C, N, D, grid = 256, 2, 128, (2, 4, 4)
+    S = 40          # 32 real tokens + 8 padded rows per sample
+    x = rb(syn.randn("rr2.x", (2 * S, C), 2))
+    w = rb(1 + syn.randn("rr2.w", (C,), 2, 0.1))
+    rope = build_rope_table(D, 4, "cuda")
+    out = torch.empty(2 * S, C, device="cuda", dtype=BF16)
+    H.rmsnorm_rope(dev(x, BF16), dev(w, BF16), out, D, 1e-6, rope=rope, rows_per_sample=S, n_rope=32, grid=grid)
+    ang = O.rope_angles(D, grid)
+    for b in range(2):
+        ref = O.rope_rotate(O.rms_norm(x[b * S:(b + 1) * S], w, 1e-6, "bf16").view(S, N, D), ang).reshape(S, C)
+        assert_bf16_close(out[b * S:(b + 1) * S], rb(ref), ulps=1.01, atol=1e-6)
+    # shard 1 of 2 (rows 20..39 of one sample)
+    out2 = torch.empty(20, C, device="cuda", dtype=BF16)
+    H.rmsnorm_rope(dev(x[20:40], BF16), dev(w, BF16), out2, D, 1e-6, rope=rope, rows_per_sample=20, tok_offset=20,
+                   n_rope=32, grid=grid)
+    assert torch.equal(out2.cpu(), out[20:40].cpu())
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (130, 256, 192), (300, 384, 1536), (257, 1536, 8960)])
+def test_gemm_epilogues(H, M, N, K):
+    a = rb(syn.randn("g.a", (M, K), 3))
+    w = rb(syn.uniform("g.w", (N, K), 1 / math.sqrt(K), 3))
+    b = rb(syn.randn("g.b", (N,), 3, 0.1))
+    acc = a @ w.t() + b
+    A, W, B = dev(a, BF16), dev(w, BF16), dev(b, BF16)
+    out = torch.empty(M, N, device="cuda", dtype=BF16)
+    H.gemm(A, W, out, B, H.EPI_BF16)
+    assert_bf16_close(out, acc, ulps=1.01, atol=2e-4)
+    H.gemm(A, W, out, B, H.EPI_BF16_GELU)
+    assert_bf16_close(out, O.gelu_tanh(rb(acc)), ulps=2.01, atol=2e-3)
+    o32 = torch.empty(M, N, device="cuda")
+    H.gemm(A, W, o32, B, H.EPI_F32)
+    assert_bf16_close(o32, acc, ulps=1.01, atol=2e-4)
+    assert torch.equal(o32.cpu(), rb(o32.cpu()))          # holds bf16-representable values
+    x0 = syn.randn("g.x0", (M, N), 3)
+    gate = syn.randn("g.gate", (N,), 3)
+    xr = dev(x0).clone()
+    H.gemm(A, W, xr, B, H.EPI_RESID, gate=dev(gate))
+    torch.testing.assert_close(xr.cpu(), x0 + rb(acc) * gate, rtol=2e-2, atol=2e-2)
+    xr = dev(x0).clone()
+    H.gemm(A, W, xr, None, H.EPI_RESID)
+    torch.testing.assert_close(xr.cpu(), x0 + rb(a @ w.t()), rtol=2e-2, atol=2e-2)
+
+
+def test_gemm_strided_views(H):
+    """Writing one third of a fused [M,3C] buffer and reading a strided A."""
+    M, C = 70, 256
+    a3 = rb(syn.randn("gs.a", (M, 3 * C), 4))
+    w = rb(syn.uniform("gs.w", (C, C), 1 / 16, 4))
+    A3 = dev(a3, BF16)
+    out3 = torch.zeros(M, 3 * C, device="cuda", dtype=BF16)
+    H.gemm(A3[:, C:2 * C], dev(w, BF16), out3[:, 2 * C:], None)
+    assert_bf16_close(out3[:, 2 * C:], a3[:, C:2 * C] @ w.t(), ulps=1.01, atol=2e-4)
+    assert float(out3[:, :2 * C].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_shapes(H):
+    z = lambda *s: torch.zeros(*s, device="cuda", dtype=BF16)
+    with pytest.raises(RuntimeError, match="K="):
+        H.gemm(z(4, 100), z(128, 100), z(4, 128))
+    with pytest.raises(RuntimeError, match="N="):
+        H.gemm(z(4, 64), z(100, 64), z(4, 100))
+    with pytest.raises(ValueError):
+        H.gemm(z(4, 64), z(128, 128), z(4, 128))
+
+
+@pytest.mark.parametrize("B,Lq,Lk,N,k_len", [
+    (1, 80, 80, 2, 72),          # tiny self-attention with padded tail
+    (1, 300, 48, 2, None),       # cross-attention, single partial tile
+    (2, 257, 257, 3, 200),       # CFG batch, ragged q block, mask inside the last tile
+    (1, 1024, 1024, 1, 1024),    # several full tiles
+    (1, 33, 700, 2, 641),        # long keys, k_len one past a tile edge
+    (1, 64, 64, 1, 1),           # a single valid key
+])
+def test_flash_attention(H, B, Lq, Lk, N, k_len):
+    D = 128
+    q = rb(syn.randn("fa.q", (B, Lq, N, D), 5))
+    k = rb(syn.randn("fa.k", (B, Lk, N, D), 5))
+    v = rb(syn.randn("fa.v", (B, Lk, N, D), 5))
+    out = torch.empty(B, Lq, N, D, device="cuda", dtype=BF16)
+    H.flash_attn(dev(q, BF16), dev(k, BF16), dev(v, BF16), out, k_len=k_len)
+    for b in range(B):
+        ref = O.attention(q[b], k[b], v[b], k_len=k_len, flow="fp32")
+        # P is rounded to bf16 before the PV product and the output is bf16: 2^-8 relative on
+        # |O| plus a small absolute term for cancellation in the weighted sum
+        assert_bf16_close(out[b], ref, ulps=2.0, atol=6e-3)
+
+
+def test_flash_attention_softmax_spike(H):
+    """One key dominates from the 3rd tile on: exercises the running-max rescale."""
+    D, L = 128, 320
+    q = rb(syn.randn("fs.q", (1, 64, 1, D), 6))
+    k = rb(syn.randn("fs.k", (1, L, 1, D), 6))
+    v = rb(syn.randn("fs.v", (1, L, 1, D), 6))
+    k[0, 150, 0] = rb(q[0, 7, 0] * 4.0)         # huge score for query 7 at key 150
+    k[0, 300, 0] = rb(q[0, 9, 0] * 6.0)
+    out = torch.empty(1, 64, 1, D, device="cuda", dtype=BF16)
+    H.flash_attn(dev(q, BF16), dev(k, BF16), dev(v, BF16), out)
+    ref = O.attention(q[0], k[0], v[0], flow="fp32")
+    assert_bf16_close(out[0], ref, ulps=2.0, atol=6e-3)
+
+
+def test_flash_attention_strided_qkv(H):
+    """q/k/v as views into one fused [B,L,3C] projection buffer."""
+    B, L, N, D = 2, 130, 2, 128
+    C = N * D
+    qkv = rb(syn.randn("fq.qkv", (B, L, 3 * C), 7))
+    Q = dev(qkv, BF16)
+    out = torch.empty(B, L, C, device="cuda", dtype=BF16)
+    H.flash_attn(Q[:, :, :C].unflatten(2, (N, D)), Q[:, :, C:2 * C].unflatten(2, (N, D)),
+                 Q[:, :, 2 * C:].unflatten(2, (N, D)), out.unflatten(2, (N, D)), k_len=100)
+    for b in range(B):
+        ref = O.attention(qkv[b, :, :C].view(L, N, D), qkv[b, :, C:2 * C].view(L, N, D),
+                          qkv[b, :, 2 * C:].view(L, N, D), k_len=100, flow="fp32")
+        assert_bf16_close(out[b].view(L, N, D), ref, ulps=2.0, atol=6e-3)
+
+
+def test_flash_attention_rejects(H):
+    z = lambda *s: torch.zeros(*s, device="cuda", dtype=BF16)
+    with pytest.raises(RuntimeError, match="head_dim"):
+        H.flash_attn(z(1, 8, 1, 64), z(1, 8, 1, 64), z(1, 8, 1, 64), z(1, 8, 1, 64))
+    with pytest.raises(RuntimeError, match="k_len"):
+        H.flash_attn(z(1, 8, 1, 128), z(1, 8, 1, 128), z(1, 8, 1, 128), z(1, 8, 1, 128), k_len=9)
+
+
+def test_patchify(H):
+    lat = syn.randn("pf.lat", (16, 3, 8, 12), 8)
+    for patch in ((1, 2, 2), (1, 4, 4)):
+        ref, grid = O.patchify(lat, patch)
+        rows = torch.empty(ref.shape, device="cuda", dtype=BF16)
+        H.patchify(dev(lat), rows, patch)
+        assert torch.equal(rows.float().cpu(), rb(ref))
+        H.patchify(dev(lat, BF16), rows, patch)
+        assert torch.equal(rows.float().cpu(), rb(ref))
+
+
+def test_time_embedding(H):
+    cfg = syn.dit_config("tiny")
+    sd = O.round_weights_bf16(syn.make_unified_state_dict(cfg, 0))
+    C = cfg["dim"]
+    ts = torch.tensor([999.0, 731.0, 208.0], dtype=torch.float64, device="cuda")
+    sin = torch.empty(256, device="cuda")
+    H.time_sinusoid(ts, sin, step=1)
+    torch.testing.assert_close(sin.cpu(), O.time_sinusoid(731.0, 256)[0].float(), rtol=0, atol=1e-6)
+    step = torch.tensor([2], dtype=torch.int32, device="cuda")
+    H.time_sinusoid(ts, sin, step_ptr=step)
+    torch.testing.assert_close(sin.cpu(), O.time_sinusoid(208.0, 256)[0].float(), rtol=0, atol=1e-6)
+    p = "wan_model."
+    g = lambda n: dev(sd[p + n], BF16)
+    e_tmp, e, e0 = (torch.empty(n, device="cuda") for n in (C, C, 6 * C))
+    H.gemv_f32(sin, g("time_embedding.0.weight"), g("time_embedding.0.bias"), e_tmp)
+    H.gemv_f32(e_tmp, g("time_embedding.2.weight"), g("time_embedding.2.bias"), e, silu_in=True)
+    H.gemv_f32(e, g("time_projection.1.weight"), g("time_projection.1.bias"), e0, silu_in=True)
+    re, re0 = O.time_embed(208.0, sd, cfg)
+    torch.testing.assert_close(e.cpu(), re, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(e0.cpu().view(6, C), re0, rtol=1e-4, atol=1e-5)
+
+
+def test_head_unpatchify(H):
+    cfg = syn.dit_config("tiny")
+    sd = O.round_weights_bf16(syn.make_unified_state_dict(cfg, 0))
+    C, grid = cfg["dim"], (3, 4, 6)
+    x = syn.randn("hd.x", (80, C), 9)
+    e = syn.randn("hd.e", (C,), 9, 0.3)
+    ref = O.head_unpatchify(x, e, sd, cfg, grid)
+    hm = torch.empty(2, C, device="cuda")
+    H.head_modulation(dev(sd["wan_model.head.modulation"].reshape(2, C), BF16), dev(e), hm)
+    y = torch.empty(80, C, device="cuda")
+    H.layernorm_modulate(dev(x), y, cfg["eps"], shift=hm[0], scale=hm[1])
+    out = torch.empty(16, 3, 8, 12, device="cuda")
+    H.head_unpatchify(y, dev(sd["wan_model.head.head.weight"], BF16), dev(sd["wan_model.head.head.bias"], BF16), out,
+                      grid, cfg["patch_size"], cfg["out_dim"])
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)

@@ -1,0 +1,78 @@
+"""Host side of the product sampler (omnivideo/utils/fm_solvers_unipc.py) on CPU: the
+schedule must equal the reference's goldens and the per-step coefficient table, applied
+by a plain-torch transcription of the fused kernel's formula, must reproduce the oracle's
+trajectory.  (The kernel itself is checked on the GPU in test_gpu_sampler.py.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from omnivideo.utils import fm_solvers_unipc as P
+from omnivideo.utils import synthetic as syn
+from oracle import unipc as U
+
+
+def linear_model(lat, t, which):
+    a = 0.9 if which == "c" else 0.7
+    return (a * lat.float() + 0.001 * float(t) * torch.sin(lat.float() * 3)).float()
+
+
+def kernel_formula(row, guide, c, u, x, last, m1, m2):
+    """What ovd_cfg_unipc_step computes per element (csrc/sampler.hip), in torch."""
+    dt = x.dtype
+    rnd = lambda v: v.to(dt).float()
+    v = u + guide * (c - u)
+    xs = x.float()
+    m_t = xs - row[P.CF_SIGMA] * v
+    xc = xs
+    if row[P.CF_USE_CORR] != 0:
+        x_t_ = rnd(row[P.CF_C_R] * last.float()) - row[P.CF_C_A] * m1
+        d1t = m_t - m1
+        if int(row[P.CF_C_ORDER]) == 1:
+            res = row[P.CF_C_RHO1] * d1t
+        else:
+            res = row[P.CF_C_RHO0] * ((m2 - m1) / row[P.CF_C_RK]) + row[P.CF_C_RHO1] * d1t
+        xc = rnd(x_t_ - row[P.CF_C_AB] * res)
+    x_t = rnd(row[P.CF_P_R] * xc) - row[P.CF_P_A] * m_t
+    if int(row[P.CF_P_ORDER]) == 2:
+        x_t = x_t - row[P.CF_P_AB] * (0.5 * ((m1 - m_t) / row[P.CF_P_RK]))
+    return x_t.to(dt), xc.to(dt), m_t, m1
+
+
+@pytest.mark.parametrize("steps,shift", [(20, 5.0), (40, 5.0), (50, 5.0), (50, 12.0)])
+def test_schedule_matches_reference_golden(golden_dir, steps, shift):
+    G = np.load(os.path.join(golden_dir, "unipc.npz"))
+    s = P.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    s.set_timesteps(steps, device="cpu", shift=shift)
+    assert np.array_equal(s.timesteps.numpy(), G[f"timesteps_{steps}_{shift:g}"])
+    assert np.array_equal(s.sigmas.numpy(), G[f"sigmas_{steps}_{shift:g}"])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("steps", [20, 3, 1])
+def test_coefficient_table_reproduces_oracle(dt, steps):
+    s = P.FlowUniPCMultistepScheduler()
+    s.set_timesteps(steps, device="cpu", shift=5.0)
+    tab = P.unipc_coefficients(s.sigmas, 2, dt)
+    assert torch.isfinite(tab).all()
+    orc = U.UniPC(steps, 5.0)
+    x = syn.randn("unipc.noise", (16, 2, 4, 6), 7).to(dt)
+    xo = x.clone()
+    last, m1, m2 = torch.zeros_like(x), torch.zeros(x.shape), torch.zeros(x.shape)
+    for i, t in enumerate(s.timesteps):
+        c, u = linear_model(x, t, "c"), linear_model(x, t, "u")
+        x, last, m1, m2 = kernel_formula(tab[i], 3.0, c, u, x, last, m1, m2)
+        co, uo = linear_model(xo, t, "c"), linear_model(xo, t, "u")
+        xo = orc.step(uo + 3.0 * (co - uo), xo)
+        if dt == torch.float32:
+            torch.testing.assert_close(x, xo, rtol=1e-5, atol=1e-6)
+        else:
+            assert torch.equal(x, xo), i
+
+
+def test_unsupported_configurations_raise():
+    with pytest.raises(NotImplementedError):
+        P.FlowUniPCMultistepScheduler(solver_order=3)
+    with pytest.raises(NotImplementedError):
+        P.FlowUniPCMultistepScheduler(solver_type="bh1")
