@@ -16,6 +16,12 @@
 // V^T fragments come from the row-major V tile through ds_read_b64_tr_b16.
 // LDS images are XOR-swizzled per 16-byte chunk so both the b128 row reads of K and
 // the transposed reads of V are bank-conflict free.
+//
+// Softmax runs in the exp2 domain with the scale folded into one FMA per score.  The
+// running maximum is only raised when a tile's maximum exceeds it by more than
+// RESCALE_THR (log2 units): probabilities then stay below 2^THR, which costs no
+// relative precision in bf16/fp32, and the 64-register rescale of O is skipped on
+// almost every tile.
 #include "common.h"
 
 namespace {
@@ -24,12 +30,25 @@ constexpr int HD = 128;        // head dim
 constexpr int BQ = 256;        // query rows per workgroup
 constexpr int BKV = 64;        // keys per tile
 constexpr int KV_TILE_BYTES = BKV * HD * 2;   // 16 KiB
+constexpr float RESCALE_THR = 6.0f;
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
 
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 256 + ((chunk ^ ((row & 3) << 2)) << 4); }
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+// full-wave combine of the two 32-lane halves: every lane gets max(x[lane], x[lane^32])
+__device__ __forceinline__ float half_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 __global__ void __launch_bounds__(512, 2)
 attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
@@ -60,44 +79,51 @@ attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, cons
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) o_acc[i][j] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_c = -1e30f;     // running maximum, already multiplied by scale_log2
+    float l_run = 0.f;      // this half's share of the row sum
 
     const int nt = (k_len + BKV - 1) / BKV;
 
-    // staging map: 512 threads x 2 chunks of 16 B per operand tile (64 rows x 16 chunks)
-    uint4 kreg[2], vreg[2];
-    auto load_tile = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + i * 512;
-            const int r = id >> 4, c = id & 15;
-            int kr = t * BKV + r;
-            kr = kr < Lk ? kr : Lk - 1;
-            kreg[i] = *reinterpret_cast<const uint4*>(Kb + (long)kr * k_ld + c * 8);
-            vreg[i] = *reinterpret_cast<const uint4*>(Vb + (long)kr * v_ld + c * 8);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        char* sk = smem + buf * KV_TILE_BYTES;
-        char* sv = smem + (2 + buf) * KV_TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + i * 512;
-            const int r = id >> 4, c = id & 15;
-            *reinterpret_cast<uint4*>(sk + k_off(r, c)) = kreg[i];
-            *reinterpret_cast<uint4*>(sv + v_off(r, c)) = vreg[i];
-        }
-    };
+    // staging map: 512 threads x 2 chunks of 16 B per operand tile (64 rows x 16 chunks);
+    // thread -> (row r0 / r0+32, chunk c0)
+    const int r0 = tid >> 4, c0 = tid & 15;
+    const int sk_w0 = k_off(r0, c0), sk_w1 = k_off(r0 + 32, c0);
+    const int sv_w0 = v_off(r0, c0), sv_w1 = v_off(r0 + 32, c0);
+    uint4 kreg0, kreg1, vreg0, vreg1;
+#define LOAD_TILE(t)                                                                     \
+    do {                                                                                 \
+        int ra = (t) * BKV + r0, rb2 = ra + 32;                                          \
+        ra = ra < Lk ? ra : Lk - 1;                                                      \
+        rb2 = rb2 < Lk ? rb2 : Lk - 1;                                                   \
+        kreg0 = *reinterpret_cast<const uint4*>(Kb + (long)ra * k_ld + c0 * 8);          \
+        kreg1 = *reinterpret_cast<const uint4*>(Kb + (long)rb2 * k_ld + c0 * 8);         \
+        vreg0 = *reinterpret_cast<const uint4*>(Vb + (long)ra * v_ld + c0 * 8);          \
+        vreg1 = *reinterpret_cast<const uint4*>(Vb + (long)rb2 * v_ld + c0 * 8);         \
+    } while (0)
+#define STORE_TILE(buf)                                                                  \
+    do {                                                                                 \
+        char* sk_ = smem + (buf) * KV_TILE_BYTES;                                        \
+        char* sv_ = smem + (2 + (buf)) * KV_TILE_BYTES;                                  \
+        *reinterpret_cast<uint4*>(sk_ + sk_w0) = kreg0;                                  \
+        *reinterpret_cast<uint4*>(sk_ + sk_w1) = kreg1;                                  \
+        *reinterpret_cast<uint4*>(sv_ + sv_w0) = vreg0;                                  \
+        *reinterpret_cast<uint4*>(sv_ + sv_w1) = vreg1;                                  \
+    } while (0)
 
-    load_tile(0);
-    store_tile(0);
+    LOAD_TILE(0);
+    STORE_TILE(0);
     __syncthreads();
+
+    // per-lane LDS read offsets (constant over tiles)
+    const int kq_off0 = k_off(l31, hi), kq_off1 = k_off(32 + l31, hi);   // + 32*ks bytes-chunk XOR handled below
+    const int g = lane >> 4, i16 = lane & 15, qd = i16 >> 2, pp = i16 & 3;
+    (void)kq_off0; (void)kq_off1;
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         const char* sk = smem + buf * KV_TILE_BYTES;
         const char* sv = smem + (2 + buf) * KV_TILE_BYTES;
-        if (t + 1 < nt) load_tile(t + 1);
+        if (t + 1 < nt) LOAD_TILE(t + 1);
 
         // ---- S^T[key][query] for 64 keys: two 32-key blocks x 8 k-steps over d
         f32x16 s[2];
@@ -106,11 +132,13 @@ attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, cons
 #pragma unroll
             for (int j = 0; j < 16; ++j) s[kb][j] = 0.f;
             const int key = kb * 32 + l31;
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(key, 2 * ks + hi));
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         // s[kb][r] is the score of key kb*32 + (r&3) + 8*(r>>2) + 4*hi against query l31
         if (t == nt - 1 && (t + 1) * BKV > k_len) {
@@ -119,30 +147,40 @@ attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= k_len) s[kb][r] = -INFINITY;
+                    if (key >= k_len) s[kb][r] = -1e30f;
                 }
         }
 
         // ---- online softmax (per query = per lane column; halves hold disjoint keys)
-        float mx = s[0][0];
+        float mx = max3(s[0][0], s[0][1], s[0][2]);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int r = 3; r < 15; r += 2) mx = max3(mx, s[0][r], s[0][r + 1]);
+        mx = max3(mx, s[0][15], s[1][0]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * scale_log2);
-        const float mb = m_new * scale_log2;
-        m_run = m_new;
-        float rs = 0.f;
+        for (int r = 1; r < 15; r += 2) mx = max3(mx, s[1][r], s[1][r + 1]);
+        mx = __builtin_fmaxf(mx, s[1][15]);
+        mx = half_max(mx) * scale_log2;
+        if (__any(mx > m_c + RESCALE_THR)) {
+            const float m_new = __builtin_fmaxf(m_c, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_c - m_new);
+            m_c = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) o_acc[i][j] *= alpha;
+        }
+        float rs0 = 0.f, rs1 = 0.f;
         bf16x8 pf[4];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             float p[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = exp2f(s[kb][r] * scale_log2 - mb);
-                rs += p[r];
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], scale_log2, -m_c));
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                rs0 += p[r];
+                rs1 += p[r + 1];
             }
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
@@ -152,42 +190,39 @@ attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, cons
                 pf[kb * 2 + h2] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
             }
         }
-        l_run = l_run * alpha + rs;
-        if (__any(alpha != 1.0f)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) o_acc[i][j] *= alpha;
-        }
+        l_run += rs0 + rs1;
 
         // ---- O^T[d][query] += V^T[d][key] P^T[key][query]; 4 k-steps of 16 keys, 4 d-blocks of 32
         // element j of the P fragment of k-step st is key 16*st + 8*(j>>2) + 4*hi + (j&3)
-        {
-            const int g = lane >> 4, i16 = lane & 15, qd = i16 >> 2, pp = i16 & 3;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int krow = 16 * st + 4 * (g >> 1) + qd;    // this lane's address row (first read)
+        for (int st = 0; st < 4; ++st) {
+            const int krow = 16 * st + 4 * (g >> 1) + qd;    // this lane's address row (first read)
+            bf16x8 vf[4];
 #pragma unroll
-                for (int db = 0; db < 4; ++db) {
-                    const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
-                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (lds_b4_ptr)(sv + v_off(krow, chunk) + 8 * (pp & 1)));
-                    const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (lds_b4_ptr)(sv + v_off(krow + 8, chunk) + 8 * (pp & 1)));
-                    const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi4);
-                    const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo2.x, lo2.y, hi2.x, hi2.y));
-                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o_acc[db], 0, 0, 0);
-                }
+            for (int db = 0; db < 4; ++db) {
+                const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds_b4_ptr)(sv + v_off(krow, chunk) + 8 * (pp & 1)));
+                const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds_b4_ptr)(sv + v_off(krow + 8, chunk) + 8 * (pp & 1)));
+                const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi4);
+                vf[db] = __builtin_bit_cast(bf16x8, make_uint4(lo2.x, lo2.y, hi2.x, hi2.y));
             }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db], pf[st], o_acc[db], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
 
-        if (t + 1 < nt) store_tile(buf ^ 1);
+        if (t + 1 < nt) STORE_TILE(buf ^ 1);
         __syncthreads();
     }
+#undef LOAD_TILE
+#undef STORE_TILE
 
     // ---- normalise and store: lane (query l31, half hi) holds d = db*32 + 8*(r>>2) + 4*hi + (r&3)
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    const float inv = 1.0f / half_sum(l_run);
     const int qr = q0 + l31;
     if (qr < Lq) {
         bf16_t* op = O + b * o_bs + (long)qr * o_ld + (long)head * HD + 4 * hi;
@@ -218,6 +253,7 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
                 "attention: token strides must keep 16-byte alignment");
     OVD_REQUIRE(q_ld >= (long)N * D && k_ld >= (long)N * D && v_ld >= (long)N * D && o_ld >= (long)N * D,
                 "attention: token stride shorter than N*D");
+    OVD_REQUIRE(softmax_scale > 0.f, "attention: softmax_scale must be positive");
     static bool attr_set = false;
     const size_t lds = 4 * KV_TILE_BYTES;
     if (!attr_set) {
