@@ -108,3 +108,90 @@ def make_special_tokens(cfg, seed=0):
     """Four learned delimiter rows (reference: unified_model.py:249-252)."""
     return {k: randn("special." + k, (1, cfg["text_dim"]), seed)
             for k in ("<img_st>", "<img_ed>", "<prp_st>", "<prp_ed>")}
+
+
+# ------------------------------------------------------------------------------ VAE
+
+def vae_config(name="wan2.1", **over):
+    """Wan 2.1 VAE hyper-parameters (reference: omnivideo/modules/vae2_1.py:596-603)."""
+    base = dict(dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2,
+                temperal_downsample=(False, True, True))
+    if name == "tiny":
+        base.update(dim=32)
+    base.update(over)
+    return base
+
+
+def _conv(sd, name, cout, cin, k, seed):
+    fan = cin * k[0] * k[1] * k[2] if len(k) == 3 else cin * k[0] * k[1]
+    bound = 1.0 / math.sqrt(fan)
+    sd[name + ".weight"] = uniform(name + ".weight", (cout, cin) + tuple(k), bound, seed)
+    sd[name + ".bias"] = uniform(name + ".bias", (cout,), bound, seed)
+
+
+def _vae_res(sd, name, cin, cout, seed):
+    sd[name + ".residual.0.gamma"] = 1.0 + randn(name + ".residual.0.gamma", (cin, 1, 1, 1), seed, 0.1)
+    _conv(sd, name + ".residual.2", cout, cin, (3, 3, 3), seed)
+    sd[name + ".residual.3.gamma"] = 1.0 + randn(name + ".residual.3.gamma", (cout, 1, 1, 1), seed, 0.1)
+    _conv(sd, name + ".residual.6", cout, cout, (3, 3, 3), seed)
+    if cin != cout:
+        _conv(sd, name + ".shortcut", cout, cin, (1, 1, 1), seed)
+
+
+def _vae_attn(sd, name, c, seed):
+    sd[name + ".norm.gamma"] = 1.0 + randn(name + ".norm.gamma", (c, 1, 1), seed, 0.1)
+    _conv(sd, name + ".to_qkv", 3 * c, c, (1, 1), seed)
+    _conv(sd, name + ".proj", c, c, (1, 1), seed)
+
+
+def make_vae_state_dict(cfg, seed=0):
+    """fp32 state dict with the key names of the reference's WanVAE_ module tree
+    (vae2_1.py:264-507): encoder / decoder / conv1 / conv2."""
+    dim, z, mult, nres = cfg["dim"], cfg["z_dim"], tuple(cfg["dim_mult"]), cfg["num_res_blocks"]
+    tdown = tuple(cfg["temperal_downsample"])
+    sd = {}
+    dims = [dim * u for u in (1,) + mult]
+    _conv(sd, "encoder.conv1", dims[0], 3, (3, 3, 3), seed)
+    idx = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(nres):
+            _vae_res(sd, f"encoder.downsamples.{idx}", cin, cout, seed)
+            cin = cout
+            idx += 1
+        if i != len(mult) - 1:
+            n = f"encoder.downsamples.{idx}"
+            _conv(sd, n + ".resample.1", cout, cout, (3, 3), seed)
+            if tdown[i]:
+                _conv(sd, n + ".time_conv", cout, cout, (3, 1, 1), seed)
+            idx += 1
+    top = dims[-1]
+    _vae_res(sd, "encoder.middle.0", top, top, seed)
+    _vae_attn(sd, "encoder.middle.1", top, seed)
+    _vae_res(sd, "encoder.middle.2", top, top, seed)
+    sd["encoder.head.0.gamma"] = 1.0 + randn("encoder.head.0.gamma", (top, 1, 1, 1), seed, 0.1)
+    _conv(sd, "encoder.head.2", 2 * z, top, (3, 3, 3), seed)
+    _conv(sd, "conv1", 2 * z, 2 * z, (1, 1, 1), seed)
+    _conv(sd, "conv2", z, z, (1, 1, 1), seed)
+    ddims = [dim * u for u in (mult[-1],) + mult[::-1]]
+    tup = tdown[::-1]
+    _conv(sd, "decoder.conv1", ddims[0], z, (3, 3, 3), seed)
+    _vae_res(sd, "decoder.middle.0", ddims[0], ddims[0], seed)
+    _vae_attn(sd, "decoder.middle.1", ddims[0], seed)
+    _vae_res(sd, "decoder.middle.2", ddims[0], ddims[0], seed)
+    idx = 0
+    for i, (cin, cout) in enumerate(zip(ddims[:-1], ddims[1:])):
+        if i in (1, 2, 3):
+            cin = cin // 2
+        for _ in range(nres + 1):
+            _vae_res(sd, f"decoder.upsamples.{idx}", cin, cout, seed)
+            cin = cout
+            idx += 1
+        if i != len(mult) - 1:
+            n = f"decoder.upsamples.{idx}"
+            _conv(sd, n + ".resample.1", cout // 2, cout, (3, 3), seed)
+            if tup[i]:
+                _conv(sd, n + ".time_conv", cout * 2, cout, (3, 1, 1), seed)
+            idx += 1
+    sd["decoder.head.0.gamma"] = 1.0 + randn("decoder.head.0.gamma", (ddims[-1], 1, 1, 1), seed, 0.1)
+    _conv(sd, "decoder.head.2", 3, ddims[-1], (3, 3, 3), seed)
+    return sd
