@@ -135,6 +135,49 @@ int ovd_cfg_unipc_step(const float* cond, const float* uncond, void* sample, voi
 /* *step_ptr += 1 on the device (advances the step counter inside a captured graph). */
 int ovd_step_advance(int* step_ptr, void* stream);
 
+/* ---- causal 3D VAE, channels-last fp32 activations [T,H,W,C] ------------------------ */
+
+/* Time-causal 3D convolution as an implicit GEMM in exact fp32:
+ *   out[t,h,w,co] = bias[co] + sum act(in[t*stride_t+kt-pad_t, h*s+kh-pad_hw, w*s+kw-pad_hw, ci]) * w[kt,kh,kw][co][ci]
+ * x [T,H,W,Cin]; frames at time index -1 / -2 (the previous chunk's tail) come from prev1 /
+ * prev2 ([H,W,Cin] each, NULL = zeros); spatial out-of-range reads are zero.
+ * w is [KT*KH*KW][Cout][Cin] fp32.  Kernel sizes: KT in {1,3}, KH = KW in {1,3}; strides 1|2.
+ * Optional input transform act(): per-voxel RMS norm x * rnorm[voxel] * sqrt(Cin) * gamma[ci]
+ * (rnorm* from ovd_vae_voxel_rnorm; gamma NULL = off) followed by SiLU when silu != 0.
+ * upsample2: the conv reads a nearest-neighbour 2x spatially upsampled view of x.
+ * time_interleave: output channel co goes to frame 2t + co/(Cout/2), channel co%(Cout/2).
+ * resid (same layout as out) is added when non-NULL.  Cin % 4 == 0.
+ * Output extent: To = (T+pad_t-KT)/stride_t+1, Ho/Wo by the usual formula (a stride-2 conv
+ * reads one zero row/column past the bottom/right edge).
+ * Replaces CausalConv3d.forward (omnivideo/modules/vae2_1.py:27-35) with its feature-cache
+ * concat, RMS_norm + SiLU (:50-53,193-197), Upsample + Conv2d and ZeroPad2d + strided
+ * Conv2d in Resample (:75-95,137-140), the time_conv frame interleave (:133-136), the
+ * strided time_conv (:155-156), the residual add of ResidualBlock (:219) and the 1x1
+ * Conv2d layers and matmuls of AttentionBlock (:245-261). */
+int ovd_vae_conv3d_f32(const float* x, const float* prev2, const float* prev1, const float* rnorm,
+                       const float* rnorm_prev2, const float* rnorm_prev1, const float* gamma, int silu,
+                       const float* w, const float* bias, const float* resid, float* out, int T, int H,
+                       int W, int Cin, int Cout, int KT, int KH, int KW, int stride_t, int stride_hw,
+                       int pad_t, int pad_hw, int upsample2, int time_interleave, void* stream);
+
+/* out[v] = 1 / max(||x[v,:]||_2, 1e-12) for nvox voxels of C channels: the denominator of
+ * F.normalize in RMS_norm.forward (vae2_1.py:50-53). */
+int ovd_vae_voxel_rnorm(const float* x, float* out, int64_t nvox, int C, void* stream);
+
+/* [C,T,H,W] -> [T,H,W,Cp] (Cp >= C, extra channels zero) with out = (in + pre[c]) * mul[c]
+ * + post[c] (each vector may be NULL); and the inverse for the first C of Cs channels with an
+ * optional clamp to [-1,1].  Layout change at the VAE boundary plus the latent
+ * (de)normalisation of WanVAE_.encode/.decode (vae2_1.py:535-539,546-550) and the output
+ * clamp of Wan2_1_VAE.decode (:660). */
+int ovd_vae_to_channels_last(const float* in, float* out, const float* pre, const float* mul,
+                             const float* post, int C, int Cp, int64_t nvox, void* stream);
+int ovd_vae_from_channels_last(const float* in, float* out, const float* pre, const float* mul,
+                               const float* post, int C, int Cs, int64_t nvox, int clamp, void* stream);
+
+/* In-place softmax(scale * s[m,:]) over M rows of length N, fp32: the softmax of
+ * F.scaled_dot_product_attention in AttentionBlock.forward (vae2_1.py:251-255). */
+int ovd_softmax_rows_f32(float* s, int M, int N, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,13 @@ int ovd_impl_head_unpatchify(const float*, long, const bf16_t*, const bf16_t*, f
 int ovd_impl_cfg_unipc_step(const float*, const float*, void*, void*, float*, float*, const float*, float,
                             const int*, int, long, int, hipStream_t);
 int ovd_impl_step_advance(int*, hipStream_t);
+int ovd_impl_conv3d_cl(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                       int, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int,
+                       int, int, int, int, int, int, hipStream_t);
+int ovd_impl_voxel_rnorm(const float*, float*, long, int, hipStream_t);
+int ovd_impl_to_cl(const float*, float*, const float*, const float*, const float*, int, int, long, hipStream_t);
+int ovd_impl_from_cl(const float*, float*, const float*, const float*, const float*, int, int, long, int, hipStream_t);
+int ovd_impl_softmax_rows(float*, int, int, float, hipStream_t);
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 #define NONNULL(p) OVD_REQUIRE((p) != nullptr, "%s: null pointer argument '%s'", __func__, #p)
@@ -132,6 +139,41 @@ int ovd_cfg_unipc_step(const float* cond, const float* uncond, void* sample, voi
 int ovd_step_advance(int* step_ptr, void* stream) {
     NONNULL(step_ptr);
     return ovd_impl_step_advance(step_ptr, ST(stream));
+}
+
+int ovd_vae_conv3d_f32(const float* x, const float* prev2, const float* prev1, const float* rnorm,
+                       const float* rnorm_prev2, const float* rnorm_prev1, const float* gamma, int silu,
+                       const float* w, const float* bias, const float* resid, float* out, int T, int H, int W, int Cin,
+                       int Cout, int KT, int KH, int KW, int stride_t, int stride_hw, int pad_t, int pad_hw,
+                       int upsample2, int time_interleave, void* stream) {
+    NONNULL(x); NONNULL(w); NONNULL(out);
+    OVD_REQUIRE((prev2 == nullptr || rnorm == nullptr) || rnorm_prev2 != nullptr, "conv3d: prev2 needs its voxel norms");
+    OVD_REQUIRE((prev1 == nullptr || rnorm == nullptr) || rnorm_prev1 != nullptr, "conv3d: prev1 needs its voxel norms");
+    return ovd_impl_conv3d_cl(x, prev2, prev1, rnorm, rnorm_prev2, rnorm_prev1, gamma, silu, w, bias, resid, out, T, H,
+                              W, Cin, Cout, KT, KH, KW, stride_t, stride_hw, pad_t, pad_hw, upsample2, time_interleave,
+                              ST(stream));
+}
+
+int ovd_vae_voxel_rnorm(const float* x, float* out, int64_t nvox, int C, void* stream) {
+    NONNULL(x); NONNULL(out);
+    return ovd_impl_voxel_rnorm(x, out, nvox, C, ST(stream));
+}
+
+int ovd_vae_to_channels_last(const float* in, float* out, const float* pre, const float* mul, const float* post, int C,
+                             int Cp, int64_t nvox, void* stream) {
+    NONNULL(in); NONNULL(out);
+    return ovd_impl_to_cl(in, out, pre, mul, post, C, Cp, nvox, ST(stream));
+}
+
+int ovd_vae_from_channels_last(const float* in, float* out, const float* pre, const float* mul, const float* post,
+                               int C, int Cs, int64_t nvox, int clamp, void* stream) {
+    NONNULL(in); NONNULL(out);
+    return ovd_impl_from_cl(in, out, pre, mul, post, C, Cs, nvox, clamp, ST(stream));
+}
+
+int ovd_softmax_rows_f32(float* s, int M, int N, float scale, void* stream) {
+    NONNULL(s);
+    return ovd_impl_softmax_rows(s, M, N, scale, ST(stream));
 }
 
 }  // extern "C"

@@ -57,3 +57,12 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Wait states covering the longest MFMA (16 passes) before its results are read by
+// non-MFMA instructions on a path where the compiler's hazard padding may not apply.
+#define MFMA_DRAIN()                                        \
+    do {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    } while (0)

@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(256) head_unpatchify_kernel(const float* __res
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b1v[s], acc1, 0, 0, 0);
         }
     }
+    MFMA_DRAIN();
     const int T_ = gf * pt, H = gh * ph, Wd = gw * pw;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {

@@ -1,0 +1,338 @@
+// Causal 3D VAE kernels, channels-last: activations are [T,H,W,C] fp32 so that one voxel's
+// channel vector is contiguous (coalesced 16-byte loads into LDS, 128-byte coalesced
+// stores of 32 output channels per voxel).
+//
+// conv3d_cl_kernel is an implicit GEMM on the matrix cores in exact fp32
+// (v_mfma_f32_32x32x2_f32: an fmaf chain, no reduced-precision inputs):
+//   out[t,h,w,co] = bias[co] + sum_{kt,kh,kw,ci} act(in[t*st+kt-pt, h*s+kh-ph, w*s+kw-ph, ci]) * W[kt,kh,kw][co][ci]
+// One workgroup = 4 waves = 128 output voxels (an 8x16 patch of one frame, or 128
+// consecutive voxels for 1x1 kernels) x 32*NB output channels.  Per (kt, 32-channel
+// chunk) the input halo patch is staged once in LDS and reused by all 9 spatial taps as
+// shifted windows; per tap the [32*NB x 32] weight slice is staged and each wave issues
+// NB*16 MFMAs (K=32).  LDS rows are padded to 36 floats so the 16-byte fragment reads of
+// 16 neighbouring voxels / weight rows land on distinct bank slots.
+// Fused into the kernel: the time-causal left context (two frame pointers from the
+// previous chunk, or zeros), per-voxel RMS norm * gamma and SiLU on the input side,
+// nearest-neighbour 2x spatial upsampling of the input, strided (downsampling) convs,
+// bias, residual add and the frame interleave of the temporal upsampler on the output
+// side.  Reference: CausalConv3d / RMS_norm / Resample / ResidualBlock in
+// omnivideo/modules/vae2_1.py:16-219.
+#include "common.h"
+
+namespace {
+
+constexpr int LDV = 36;              // floats per staged voxel / weight row (32 + 4 pad)
+constexpr int MAX_HALO = 17 * 33;    // stride-2 3x3 conv on an 8x16 tile
+
+struct ConvArgs {
+    const float* x; const float* prev2; const float* prev1;      // frames t>=0, t=-2, t=-1
+    const float* rn; const float* rn_prev2; const float* rn_prev1;   // per-voxel 1/||x|| (or null)
+    const float* gamma; const float* w; const float* bias; const float* resid; float* out;
+    int T, H, W, Cin, Cout, To, Ho, Wo;
+    int KT, KH, KW, st, s, pt, ph;       // kernel, temporal stride, spatial stride, paddings
+    int ups, til, silu, TW;              // input 2x upsample, time-interleaved output, SiLU, tile width
+    float norm_scale;                    // sqrt(Cin) when gamma != null
+};
+
+template <int NB>
+__global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* halo = lds;                          // [HR*WR][LDV]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TW = a.TW, TH = 128 / TW;
+    const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tw_i = bid % tiles_w; bid /= tiles_w;
+    const int th_i = bid % tiles_h;
+    const int to = bid / tiles_h;
+    const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int n0 = blockIdx.y * 32 * NB;
+
+    // halo rectangle in source coordinates
+    int hs0, ws0, HR, WR;
+    if (a.ups) {
+        hs0 = (h0 - 1) >> 1; ws0 = (w0 - 1) >> 1;
+        HR = ((h0 + TH) >> 1) - hs0 + 1; WR = ((w0 + TW) >> 1) - ws0 + 1;
+    } else {
+        hs0 = h0 * a.s - a.ph; ws0 = w0 * a.s - a.ph;
+        HR = (TH - 1) * a.s + a.KH; WR = (TW - 1) * a.s + a.KW;
+    }
+    float* wt = lds + HR * WR * LDV;             // [32*NB][LDV]
+
+    // this lane's output voxel inside the tile (A-operand row) and its halo index per tap
+    const int iv = wave * 32 + (lane & 31);
+    const int dh = iv / TW, dw = iv % TW;
+    const int kq = lane >> 5;                    // which half of the k pairs this lane feeds
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[nb][j] = 0.f;
+
+    const int nchunk = (a.Cin + 31) >> 5;
+    const long frame_elems = (long)a.H * a.W * a.Cin;
+    for (int kt = 0; kt < a.KT; ++kt) {
+        const int ts = to * a.st + kt - a.pt;
+        const float* fp; const float* rp;
+        if (ts >= 0) { fp = a.x + ts * frame_elems; rp = a.rn ? a.rn + (long)ts * a.H * a.W : nullptr; }
+        else if (ts == -1) { fp = a.prev1; rp = a.rn_prev1; }
+        else { fp = a.prev2; rp = a.rn_prev2; }
+        if (fp == nullptr) continue;             // zero padding contributes nothing
+        for (int cc = 0; cc < nchunk; ++cc) {
+            __syncthreads();                      // previous users of halo / wt are done
+            for (int idx = tid; idx < HR * WR * 8; idx += 256) {
+                const int v = idx >> 3, j = idx & 7;
+                const int hs = hs0 + v / WR, ws = ws0 + v % WR;
+                const int ci = cc * 32 + 4 * j;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (hs >= 0 && hs < a.H && ws >= 0 && ws < a.W && ci < a.Cin) {
+                    val = *reinterpret_cast<const float4*>(fp + ((long)hs * a.W + ws) * a.Cin + ci);
+                    if (a.gamma) {
+                        const float r = rp[(long)hs * a.W + ws] * a.norm_scale;
+                        const float4 g = *reinterpret_cast<const float4*>(a.gamma + ci);
+                        val.x = val.x * r * g.x; val.y = val.y * r * g.y;
+                        val.z = val.z * r * g.z; val.w = val.w * r * g.w;
+                    }
+                    if (a.silu) {
+                        val.x = val.x / (1.f + expf(-val.x)); val.y = val.y / (1.f + expf(-val.y));
+                        val.z = val.z / (1.f + expf(-val.z)); val.w = val.w / (1.f + expf(-val.w));
+                    }
+                }
+                *reinterpret_cast<float4*>(halo + v * LDV + 4 * j) = val;
+            }
+            const int ksteps = (min(32, a.Cin - cc * 32) + 7) >> 3;
+            for (int kh = 0; kh < a.KH; ++kh)
+                for (int kw = 0; kw < a.KW; ++kw) {
+                    const int tap = (kt * a.KH + kh) * a.KW + kw;
+                    if (kh + kw > 0) __syncthreads();          // wt is being re-staged
+                    for (int idx = tid; idx < 32 * NB * 8; idx += 256) {
+                        const int r = idx >> 3, j = idx & 7;
+                        const int co = n0 + r, ci = cc * 32 + 4 * j;
+                        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (co < a.Cout && ci < a.Cin)
+                            val = *reinterpret_cast<const float4*>(a.w + ((long)tap * a.Cout + co) * a.Cin + ci);
+                        *reinterpret_cast<float4*>(wt + r * LDV + 4 * j) = val;
+                    }
+                    __syncthreads();
+                    int hsrc, wsrc;
+                    if (a.ups) { hsrc = ((h0 + dh + kh - 1) >> 1) - hs0; wsrc = ((w0 + dw + kw - 1) >> 1) - ws0; }
+                    else { hsrc = dh * a.s + kh; wsrc = dw * a.s + kw; }
+                    const float* ap = halo + (hsrc * WR + wsrc) * LDV + 4 * kq;
+                    const float* bp = wt + (lane & 31) * LDV + 4 * kq;
+                    for (int k8 = 0; k8 < ksteps; ++k8) {
+                        const float4 av = *reinterpret_cast<const float4*>(ap + 8 * k8);
+                        const float avv[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const float4 bv = *reinterpret_cast<const float4*>(bp + nb * 32 * LDV + 8 * k8);
+                            const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[q], bvv[q], acc[nb], 0, 0, 0);
+                        }
+                    }
+                    // hipcc (ROCm 7.2) copies the accumulators out of the AGPR file at this loop
+                    // exit and pads the MFMA -> accvgpr_read hazard only for some of the 16
+                    // registers across the branch (the last-written register came back stale with
+                    // NB == 1).  32 wait states cover the 16-pass MFMA; < 3 % of a tap's MFMA time.
+                    MFMA_DRAIN();
+                }
+        }
+    }
+
+    // The last MFMA of the loop nest retires its 16 result registers over 64 cycles; with a
+    // single accumulator (NB == 1) nothing separates it from the reads below and hipcc's
+    // hazard padding does not reach across the nested-loop exit (the last register came back
+    // stale).  Pad explicitly.
+    MFMA_DRAIN();
+    // epilogue: D row = voxel (reg&3)+8*(reg>>2)+4*kq of this wave's 32, column = lane&31 = channel
+    const int C_out_row = a.til ? a.Cout / 2 : a.Cout;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int co = n0 + nb * 32 + (lane & 31);
+        if (co >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.f;
+        int frame = to, cch = co;
+        if (a.til) { frame = 2 * to + co / C_out_row; cch = co % C_out_row; }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
+            const int ho = h0 + ov / TW, wo = w0 + ov % TW;
+            if (ho >= a.Ho || wo >= a.Wo) continue;
+            const long o = (((long)frame * a.Ho + ho) * a.Wo + wo) * C_out_row + cch;
+            float v = acc[nb][reg] + bv;
+            if (a.resid) v += a.resid[o];
+            a.out[o] = v;
+        }
+    }
+}
+
+// 1 / max(||x_v||_2, 1e-12) per voxel (F.normalize's denominator, vae2_1.py:50-53)
+__global__ void __launch_bounds__(256) voxel_rnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          long nvox, int C) {
+    const int lane = threadIdx.x & 63;
+    const long v = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= nvox) return;
+    const float4* p = reinterpret_cast<const float4*>(x + v * C);
+    float s = 0.f;
+    for (int i = lane; i < C / 4; i += 64) {
+        const float4 q = p[i];
+        s += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[v] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+}
+
+// [C,T,H,W] -> [T,H,W,Cp] with out = (in + pre[c]) * mul[c] + post[c]; channels >= C are zero
+__global__ void to_cl_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ pre,
+                             const float* __restrict__ mul, const float* __restrict__ post, int C, int Cp,
+                             long nvox) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nvox * Cp) return;
+    const int c = (int)(idx % Cp);
+    const long v = idx / Cp;
+    float val = 0.f;
+    if (c < C) {
+        val = in[(long)c * nvox + v];
+        if (pre) val += pre[c];
+        if (mul) val *= mul[c];
+        if (post) val += post[c];
+    }
+    out[idx] = val;
+}
+
+// [T,H,W,Cs] (first C channels) -> [C,T,H,W] with the same affine, optional clamp to [-1,1]
+__global__ void from_cl_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ pre,
+                               const float* __restrict__ mul, const float* __restrict__ post, int C, int Cs,
+                               long nvox, int clamp) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nvox * C) return;
+    const long v = idx % nvox;
+    const int c = (int)(idx / nvox);
+    float val = in[v * Cs + c];
+    if (pre) val += pre[c];
+    if (mul) val *= mul[c];
+    if (post) val += post[c];
+    if (clamp) val = fminf(fmaxf(val, -1.f), 1.f);
+    out[idx] = val;
+}
+
+// in-place softmax(scale * row) over rows of length N (fp32), one workgroup per row
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ s, int N, float scale) {
+    __shared__ float red[8];
+    float* row = s + (long)blockIdx.x * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, row[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < N; i += 256) {
+        const float e = expf((row[i] - mx) * scale);
+        row[i] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int i = tid; i < N; i += 256) row[i] *= inv;
+}
+
+}  // namespace
+
+int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, const float* rn, const float* rn_prev2,
+                       const float* rn_prev1, const float* gamma, int silu, const float* w, const float* bias,
+                       const float* resid, float* out, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW,
+                       int stride_t, int stride_hw, int pad_t, int pad_hw, int upsample2, int time_interleave,
+                       hipStream_t st) {
+    OVD_REQUIRE(T > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d: empty tensor");
+    OVD_REQUIRE(Cin % 4 == 0, "conv3d: Cin=%d must be a multiple of 4 (pad the channels)", Cin);
+    OVD_REQUIRE((KT == 1 || KT == 3) && (KH == 1 || KH == 3) && KH == KW, "conv3d: kernel %dx%dx%d not built", KT, KH, KW);
+    OVD_REQUIRE(stride_t >= 1 && stride_t <= 2 && stride_hw >= 1 && stride_hw <= 2, "conv3d: stride not built");
+    OVD_REQUIRE(pad_t >= 0 && pad_t <= 2 && pad_hw >= 0 && pad_hw <= 1, "conv3d: padding not built");
+    OVD_REQUIRE(!(upsample2 && (stride_hw != 1 || KH != 3 || pad_hw != 1)), "conv3d: upsample needs a 3x3 stride-1 pad-1 conv");
+    OVD_REQUIRE(!(time_interleave && Cout % 2), "conv3d: time interleave needs an even Cout");
+    OVD_REQUIRE((gamma == nullptr) == (rn == nullptr), "conv3d: gamma and the voxel norms come together");
+    const int Hin = upsample2 ? 2 * H : H, Win = upsample2 ? 2 * W : W;
+    const int Ho = (Hin + 2 * pad_hw - KH + (stride_hw == 2 ? 1 : 0)) / stride_hw + 1 - (stride_hw == 2 ? 0 : 0);
+    const int Wo = (Win + 2 * pad_hw - KW + (stride_hw == 2 ? 1 : 0)) / stride_hw + 1;
+    // temporal extent: `pad_t` frames of left context (previous-chunk frames or zeros)
+    const int To = (T + pad_t - KT) / stride_t + 1;
+    OVD_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "conv3d: output would be empty");
+    ConvArgs a;
+    a.x = x; a.prev2 = prev2; a.prev1 = prev1; a.rn = rn; a.rn_prev2 = rn_prev2; a.rn_prev1 = rn_prev1;
+    a.gamma = gamma; a.w = w; a.bias = bias; a.resid = resid; a.out = out;
+    a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.To = To; a.Ho = Ho; a.Wo = Wo;
+    a.KT = KT; a.KH = KH; a.KW = KW; a.st = stride_t; a.s = stride_hw; a.pt = pad_t; a.ph = pad_hw;
+    a.ups = upsample2; a.til = time_interleave; a.silu = silu;
+    a.TW = (KH == 1) ? 128 : 16;
+    a.norm_scale = sqrtf((float)Cin);
+    if (KH == 1) {      // 1x1: voxels are independent, flatten H*W into one axis of 128-voxel tiles
+        a.W = H * W; a.H = 1; a.Wo = Ho * Wo; a.Ho = 1;
+    }
+    const int TW = a.TW, TH = 128 / TW;
+    const int tiles = ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH) * To;
+    int HR, WR;
+    if (upsample2) { HR = TH / 2 + 2; WR = TW / 2 + 2; }
+    else { HR = (TH - 1) * stride_hw + KH; WR = (TW - 1) * stride_hw + KW; }
+    OVD_REQUIRE(HR * WR <= MAX_HALO, "conv3d: halo too large");
+    const int nb = Cout > 96 ? 4 : (Cout > 32 ? 3 : 1);
+    const size_t lds = (size_t)(HR * WR + 32 * nb) * LDV * sizeof(float);
+    dim3 grid(tiles, ceil_div(Cout, 32 * nb)), blk(256);
+#define CONV_CASE(NBV)                                                                                         \
+    case NBV: {                                                                                                \
+        static size_t cur = 0;                                                                                 \
+        if (lds > cur) {                                                                                       \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_cl_kernel<NBV>),                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)       \
+                OVD_FAIL("conv3d: cannot reserve %zu bytes of LDS", lds);                                      \
+            cur = lds;                                                                                         \
+        }                                                                                                      \
+        hipLaunchKernelGGL(conv3d_cl_kernel<NBV>, grid, blk, lds, st, a);                                      \
+    } break;
+    switch (nb) { CONV_CASE(1) CONV_CASE(3) CONV_CASE(4) }
+#undef CONV_CASE
+    OVD_CHECK_LAUNCH("conv3d_cl");
+    return 0;
+}
+
+int ovd_impl_voxel_rnorm(const float* x, float* out, long nvox, int C, hipStream_t st) {
+    OVD_REQUIRE(C % 4 == 0 && C > 0, "voxel_rnorm: C must be a multiple of 4");
+    if (nvox == 0) return 0;
+    hipLaunchKernelGGL(voxel_rnorm_kernel, dim3(ceil_div(nvox, 4)), dim3(256), 0, st, x, out, nvox, C);
+    OVD_CHECK_LAUNCH("voxel_rnorm");
+    return 0;
+}
+
+int ovd_impl_to_cl(const float* in, float* out, const float* pre, const float* mul, const float* post, int C, int Cp,
+                   long nvox, hipStream_t st) {
+    OVD_REQUIRE(Cp >= C && C > 0, "to_channels_last: padded channel count smaller than C");
+    if (nvox == 0) return 0;
+    hipLaunchKernelGGL(to_cl_kernel, dim3(ceil_div(nvox * Cp, 256)), dim3(256), 0, st, in, out, pre, mul, post, C, Cp,
+                       nvox);
+    OVD_CHECK_LAUNCH("to_channels_last");
+    return 0;
+}
+
+int ovd_impl_from_cl(const float* in, float* out, const float* pre, const float* mul, const float* post, int C, int Cs,
+                     long nvox, int clamp, hipStream_t st) {
+    OVD_REQUIRE(Cs >= C && C > 0, "from_channels_last: source has fewer channels than requested");
+    if (nvox == 0) return 0;
+    hipLaunchKernelGGL(from_cl_kernel, dim3(ceil_div(nvox * C, 256)), dim3(256), 0, st, in, out, pre, mul, post, C, Cs,
+                       nvox, clamp);
+    OVD_CHECK_LAUNCH("from_channels_last");
+    return 0;
+}
+
+int ovd_impl_softmax_rows(float* s, int M, int N, float scale, hipStream_t st) {
+    OVD_REQUIRE(M >= 0 && N > 0, "softmax: bad shape");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, st, s, N, scale);
+    OVD_CHECK_LAUNCH("softmax_rows");
+    return 0;
+}

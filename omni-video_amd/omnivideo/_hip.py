@@ -28,6 +28,11 @@ SIGNATURES = {
     "ovd_head_unpatchify": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_cfg_unipc_step": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
     "ovd_step_advance": [_p, _p],
+    "ovd_vae_conv3d_f32": [_p] * 7 + [_i] + [_p] * 4 + [_i] * 14 + [_p],
+    "ovd_vae_voxel_rnorm": [_p, _p, _l, _i, _p],
+    "ovd_vae_to_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _p],
+    "ovd_vae_from_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
+    "ovd_softmax_rows_f32": [_p, _i, _i, _f, _p],
 }
 
 EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_RESID = 0, 1, 2, 3
@@ -229,3 +234,77 @@ def cfg_unipc_step(cond, uncond, sample, last_sample, m1, m2, coef, guide_scale,
 
 def step_advance(step_ptr):
     _call("ovd_step_advance", _ptr(step_ptr, torch.int32), _stream())
+
+
+# ---------------------------------------------------------------------------- VAE (channels-last fp32)
+
+def _f32c(t, allow_none=False):
+    if t is None:
+        return _ptr(None, allow_none=allow_none)
+    if not t.is_contiguous():
+        raise ValueError("VAE kernels need contiguous tensors")
+    return _ptr(t, F32)
+
+
+def vae_conv3d(x, w, bias, kernel, prev2=None, prev1=None, rnorm=None, rnorm_prev2=None, rnorm_prev1=None,
+               gamma=None, silu=False, resid=None, stride_t=1, stride_hw=1, pad_t=0, pad_hw=0, upsample2=False,
+               time_interleave=False, out=None):
+    """x [T,H,W,Cin] fp32, w [KT*KH*KW, Cout, Cin] fp32 -> [To,Ho,Wo,Cout] (or the frame-interleaved
+    [2To,Ho,Wo,Cout/2]).  prev1/prev2 are the [H,W,Cin] frames at time -1/-2 (None = zeros)."""
+    T, H, W, Cin = x.shape
+    KT, KH, KW = kernel
+    taps, Cout, Cin_w = w.shape
+    if taps != KT * KH * KW or Cin_w != Cin:
+        raise ValueError(f"conv3d: weight {tuple(w.shape)} does not match kernel {kernel} / Cin {Cin}")
+    for p in (prev1, prev2):
+        if p is not None and tuple(p.shape) != (H, W, Cin):
+            raise ValueError("conv3d: previous-chunk frame has the wrong shape")
+    Hin, Win = (2 * H, 2 * W) if upsample2 else (H, W)
+    Ho = (Hin + 2 * pad_hw - KH + (1 if stride_hw == 2 else 0)) // stride_hw + 1
+    Wo = (Win + 2 * pad_hw - KW + (1 if stride_hw == 2 else 0)) // stride_hw + 1
+    To = (T + pad_t - KT) // stride_t + 1
+    shape = (2 * To, Ho, Wo, Cout // 2) if time_interleave else (To, Ho, Wo, Cout)
+    if out is None:
+        out = torch.empty(shape, dtype=F32, device=x.device)
+    elif tuple(out.shape) != shape:
+        raise ValueError(f"conv3d: out has shape {tuple(out.shape)}, expected {shape}")
+    if resid is not None and tuple(resid.shape) != shape:
+        raise ValueError("conv3d: residual shape mismatch")
+    _call("ovd_vae_conv3d_f32", _f32c(x), _f32c(prev2, True), _f32c(prev1, True), _f32c(rnorm, True),
+          _f32c(rnorm_prev2, True), _f32c(rnorm_prev1, True), _f32c(gamma, True), int(silu), _f32c(w),
+          _f32c(bias, True), _f32c(resid, True), _f32c(out), T, H, W, Cin, Cout, KT, KH, KW, stride_t, stride_hw,
+          pad_t, pad_hw, int(upsample2), int(time_interleave), _stream())
+    return out
+
+
+def vae_voxel_rnorm(x):
+    C = x.shape[-1]
+    out = torch.empty(x.shape[:-1], dtype=F32, device=x.device)
+    _call("ovd_vae_voxel_rnorm", _f32c(x), _f32c(out), x.numel() // C, C, _stream())
+    return out
+
+
+def vae_to_channels_last(x, c_pad=None, pre=None, mul=None, post=None):
+    """[C,T,H,W] -> [T,H,W,c_pad] fp32."""
+    C, T, H, W = x.shape
+    cp = C if c_pad is None else c_pad
+    out = torch.empty(T, H, W, cp, dtype=F32, device=x.device)
+    _call("ovd_vae_to_channels_last", _f32c(x), _f32c(out), _f32c(pre, True), _f32c(mul, True), _f32c(post, True), C,
+          cp, T * H * W, _stream())
+    return out
+
+
+def vae_from_channels_last(x, channels=None, pre=None, mul=None, post=None, clamp=False):
+    """[T,H,W,Cs] -> [C,T,H,W] (first C channels)."""
+    T, H, W, Cs = x.shape
+    C = Cs if channels is None else channels
+    out = torch.empty(C, T, H, W, dtype=F32, device=x.device)
+    _call("ovd_vae_from_channels_last", _f32c(x), _f32c(out), _f32c(pre, True), _f32c(mul, True), _f32c(post, True),
+          C, Cs, T * H * W, int(clamp), _stream())
+    return out
+
+
+def softmax_rows(s, scale):
+    M, N = s.shape
+    _call("ovd_softmax_rows_f32", _f32c(s), M, N, float(scale), _stream())
+    return s

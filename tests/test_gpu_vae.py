@@ -1,0 +1,188 @@
+"""VAE parity on the GPU: the fused channels-last conv kernel against torch's fp32 conv on
+the CPU for every mode the VAE uses, then whole encode / decode of the reduced-width VAE
+through the reference-named `Wan2_1_VAE` surface against the oracle and against the
+goldens made by the reference's own WanVAE_.  Tolerance: fp32 round-off (the kernels are
+exact-fp32 MFMA; only the summation order differs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from omnivideo.utils import synthetic as syn
+from oracle import vae as V
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 2e-4, 2e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    import omnivideo._hip as H
+    H.lib()
+    return H
+
+
+def cl(x):           # [C,T,H,W] -> [T,H,W,C] on the device
+    return x.permute(1, 2, 3, 0).contiguous().cuda()
+
+
+def cf(y):           # back
+    return y.cpu().permute(3, 0, 1, 2).contiguous()
+
+
+def prep_w(w):
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    co, ci = w.shape[:2]
+    return w.permute(2, 3, 4, 0, 1).reshape(-1, co, ci).contiguous().cuda(), tuple(w.shape[2:])
+
+
+@pytest.mark.parametrize("cin,cout,T,Hh,Ww", [(32, 32, 3, 9, 17), (64, 96, 1, 8, 16), (16, 128, 2, 5, 7), (4, 32, 4, 12, 20),
+                                              (96, 3, 2, 10, 33), (128, 160, 1, 4, 6)])
+def test_causal_conv333_with_context(H, cin, cout, T, Hh, Ww):
+    x = syn.randn("cv.x", (cin, T, Hh, Ww), 1)
+    ctx = syn.randn("cv.ctx", (cin, 2, Hh, Ww), 1)
+    w = syn.uniform("cv.w", (cout, cin, 3, 3, 3), (27 * cin) ** -0.5, 1)
+    b = syn.randn("cv.b", (cout,), 1, 0.1)
+    wk, k = prep_w(w)
+    for ncache in (0, 1, 2):
+        cache = ctx[:, 2 - ncache:] if ncache else None
+        ref = V.causal_conv(x, w, b, cache)
+        c = cl(ctx)
+        y = H.vae_conv3d(cl(x), wk, b.cuda(), k, prev2=c[0] if ncache == 2 else None,
+                         prev1=c[1] if ncache >= 1 else None, pad_t=2, pad_hw=1)
+        torch.testing.assert_close(cf(y), ref, rtol=RTOL, atol=ATOL)
+
+
+def test_conv_fused_norm_silu_residual(H):
+    cin, cout, T, Hh, Ww = 64, 64, 2, 9, 11
+    x = syn.randn("cn.x", (cin, T, Hh, Ww), 2)
+    ctx = syn.randn("cn.ctx", (cin, 2, Hh, Ww), 2)
+    g = 1 + syn.randn("cn.g", (cin,), 2, 0.1)
+    w = syn.uniform("cn.w", (cout, cin, 3, 3, 3), (27 * cin) ** -0.5, 2)
+    b = syn.randn("cn.b", (cout,), 2, 0.1)
+    res = syn.randn("cn.r", (cout, T, Hh, Ww), 2)
+    act = lambda t: F.silu(V.rms_norm(t, g))
+    ref = V.causal_conv(act(x), w, b, act(ctx)) + res
+    wk, k = prep_w(w)
+    xc, cc = cl(x), cl(ctx)
+    rn, rc = H.vae_voxel_rnorm(xc), H.vae_voxel_rnorm(cc)
+    torch.testing.assert_close(rn.cpu(), 1.0 / x.norm(dim=0).clamp_min(1e-12), rtol=1e-5, atol=1e-7)
+    y = H.vae_conv3d(xc, wk, b.cuda(), k, prev2=cc[0], prev1=cc[1], rnorm=rn, rnorm_prev2=rc[0], rnorm_prev1=rc[1],
+                     gamma=g.cuda(), silu=True, resid=cl(res), pad_t=2, pad_hw=1)
+    torch.testing.assert_close(cf(y), ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("Hh,Ww", [(6, 10), (8, 16), (5, 9)])
+def test_upsample_conv_and_downsample_conv(H, Hh, Ww):
+    c = 64
+    x = syn.randn("ud.x", (c, 2, Hh, Ww), 3)
+    w = syn.uniform("ud.w", (c // 2, c, 3, 3), (9 * c) ** -0.5, 3)
+    b = syn.randn("ud.b", (c // 2,), 3, 0.1)
+    up = F.interpolate(x.permute(1, 0, 2, 3), scale_factor=(2.0, 2.0), mode="nearest-exact")
+    ref = F.conv2d(up, w, b, padding=1).permute(1, 0, 2, 3)
+    wk, k = prep_w(w)
+    y = H.vae_conv3d(cl(x), wk, b.cuda(), k, pad_hw=1, upsample2=True)
+    torch.testing.assert_close(cf(y), ref, rtol=RTOL, atol=ATOL)
+    w2 = syn.uniform("ud.w2", (c, c, 3, 3), (9 * c) ** -0.5, 3)
+    ref = F.conv2d(F.pad(x.permute(1, 0, 2, 3), (0, 1, 0, 1)), w2, None, stride=2).permute(1, 0, 2, 3)
+    wk, k = prep_w(w2)
+    y = H.vae_conv3d(cl(x), wk, None, k, stride_hw=2, pad_hw=0)
+    torch.testing.assert_close(cf(y), ref, rtol=RTOL, atol=ATOL)
+
+
+def test_time_convs(H):
+    c, T, Hh, Ww = 32, 3, 5, 6
+    x = syn.randn("tc.x", (c, T, Hh, Ww), 4)
+    ctx = syn.randn("tc.ctx", (c, 2, Hh, Ww), 4)
+    # temporal upsampler: (3,1,1) conv to 2C channels, frames interleaved (vae2_1.py:127-136)
+    w = syn.uniform("tc.w", (2 * c, c, 3, 1, 1), (3 * c) ** -0.5, 4)
+    b = syn.randn("tc.b", (2 * c,), 4, 0.1)
+    y = V.causal_conv(x, w, b, ctx).reshape(2, c, T, Hh, Ww)
+    ref = torch.stack((y[0], y[1]), dim=2).reshape(c, 2 * T, Hh, Ww)
+    wk, k = prep_w(w)
+    cc = cl(ctx)
+    got = H.vae_conv3d(cl(x), wk, b.cuda(), k, prev2=cc[0], prev1=cc[1], pad_t=2, time_interleave=True)
+    torch.testing.assert_close(cf(got), ref, rtol=RTOL, atol=ATOL)
+    # temporal downsampler: (3,1,1) stride 2 over [last cached frame | chunk] (vae2_1.py:155-156)
+    x4 = syn.randn("tc.x4", (c, 4, Hh, Ww), 4)
+    w2 = syn.uniform("tc.w2", (c, c, 3, 1, 1), (3 * c) ** -0.5, 4)
+    ref = F.conv3d(torch.cat([ctx[:, -1:], x4], 1)[None], w2, None, stride=(2, 1, 1))[0]
+    wk, k = prep_w(w2)
+    got = H.vae_conv3d(cl(x4), wk, None, k, prev1=cc[1], stride_t=2, pad_t=1)
+    torch.testing.assert_close(cf(got), ref, rtol=RTOL, atol=ATOL)
+
+
+def test_layout_and_softmax(H):
+    z = syn.randn("lo.z", (16, 3, 4, 5), 5)
+    a, m, p = syn.randn("lo.a", (16,), 5), syn.randn("lo.m", (16,), 5), syn.randn("lo.p", (16,), 5)
+    y = H.vae_to_channels_last(z.cuda(), c_pad=20, pre=a.cuda(), mul=m.cuda(), post=p.cuda())
+    ref = ((z + a.view(-1, 1, 1, 1)) * m.view(-1, 1, 1, 1) + p.view(-1, 1, 1, 1)).permute(1, 2, 3, 0)
+    torch.testing.assert_close(y.cpu()[..., :16], ref, rtol=1e-6, atol=1e-6)
+    assert float(y[..., 16:].abs().max()) == 0.0
+    back = H.vae_from_channels_last(y, channels=16, clamp=True)
+    torch.testing.assert_close(back.cpu(), ref.permute(3, 0, 1, 2).clamp(-1, 1), rtol=1e-6, atol=1e-6)
+    s = syn.randn("lo.s", (37, 300), 5, 3.0)
+    got = H.softmax_rows(s.cuda().clone(), 0.25)
+    torch.testing.assert_close(got.cpu(), torch.softmax(s * 0.25, dim=-1), rtol=1e-5, atol=1e-7)
+
+
+def test_conv_rejects(H):
+    x = torch.zeros(1, 4, 4, 6, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        H.vae_conv3d(x, torch.zeros(27, 8, 6, device="cuda"), None, (3, 3, 3), pad_t=2, pad_hw=1)
+    with pytest.raises(ValueError):
+        H.vae_conv3d(x[..., :4].contiguous(), torch.zeros(9, 8, 4, device="cuda"), None, (3, 3, 3))
+
+
+# --------------------------------------------------------------------------------- whole model
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "vae_tiny.npz")).items()}
+
+
+@pytest.fixture(scope="module")
+def vae():
+    from omnivideo.modules.vae2_1 import Wan2_1_VAE
+    cfg = syn.vae_config("tiny")
+    v = Wan2_1_VAE(z_dim=cfg["z_dim"], vae_pth=None, device="cuda", dim=cfg["dim"])
+    sd = syn.make_vae_state_dict(cfg, 0)
+    v.model.load_state_dict(sd, strict=True)
+    lay = V.vae_layout(cfg["dim"], cfg["z_dim"], cfg["dim_mult"], cfg["num_res_blocks"], cfg["temperal_downsample"])
+    return v, sd, lay
+
+
+def test_state_dict_keys(vae):
+    v, sd, _ = vae
+    assert set(v.model.state_dict().keys()) == set(sd.keys())
+
+
+@pytest.mark.parametrize("frames,hw", [(5, (32, 48)), (9, (32, 32)), (1, (16, 16))])
+def test_encode(vae, G, frames, hw):
+    v, sd, lay = vae
+    vid = syn.randn(f"vae.video{frames}", (3, frames, *hw), 5).clamp(-1, 1)
+    z = v.encode([vid.cuda()])[0]
+    torch.testing.assert_close(z.cpu(), G[f"encode_{frames}"], rtol=1e-3, atol=1e-4)
+    with torch.no_grad():
+        torch.testing.assert_close(z.cpu(), V.encode(vid, sd, lay), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("tl,hw", [(2, (4, 6)), (3, (4, 4)), (1, (2, 2))])
+def test_decode(vae, G, tl, hw):
+    v, sd, lay = vae
+    z = syn.randn(f"vae.z{tl}", (16, tl, *hw), 5)
+    x = v.decode([z.cuda()])[0]
+    assert tuple(x.shape) == (3, 4 * tl - 3, 8 * hw[0], 8 * hw[1])
+    torch.testing.assert_close(x.cpu(), G[f"decode_{tl}"], rtol=1e-3, atol=1e-4)
+
+
+def test_decode_encode_round_trip_shapes(vae):
+    """decode -> encode keeps the latent geometry (size-independent property)."""
+    v, _, _ = vae
+    z = syn.randn("vae.rt", (16, 3, 4, 6), 6)
+    x = v.decode([z.cuda()])[0]
+    z2 = v.encode([x])[0]
+    assert tuple(z2.shape) == tuple(z.shape) and torch.isfinite(z2).all()
