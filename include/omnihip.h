@@ -112,12 +112,15 @@ int ovd_head_modulation(const uint16_t* mod, const float* e, float* out, int C, 
 
 /* Head projection in exact fp32 fused with the unpatchify scatter:
  * out[c][f*pt+p][h*ph+q][w*pw+r] = y[tok(f,h,w)] . W[(p,q,r,c)] + bias, with
- * out_dim*pt*ph*pw == 64.  y is the normalised + modulated fp32 activation [n_tok.., C].
+ * out_dim*pt*ph*pw == 64.  y is the normalised + modulated fp32 activation; its first n_tok
+ * rows hold tokens tok_offset .. tok_offset+n_tok-1 (a sequence-parallel rank passes its
+ * shard; rows past the grid's f*h*w tokens are skipped).  Only those tokens' outputs are
+ * written.
  * Replaces Head.head under float32 autocast (model.py:285-289) and WanModel.unpatchify
  * (model.py:526-549). */
 int ovd_head_unpatchify(const float* y, int64_t ldy, const uint16_t* W, const uint16_t* bias, float* out,
                         int n_tok, int C, int Cout, int pt, int ph, int pw, int gf, int gh, int gw,
-                        void* stream);
+                        int tok_offset, void* stream);
 
 /* One sampling step on n latent elements:
  *   v = uncond + guide * (cond - uncond)                 (x2x_gen_unified.py:484)

@@ -29,7 +29,7 @@ int ovd_impl_gemv_f32(const float*, const bf16_t*, const bf16_t*, float*, int, i
 int ovd_impl_modulation(const bf16_t* const*, const float*, float*, int, int, hipStream_t);
 int ovd_impl_head_modulation(const bf16_t*, const float*, float*, int, hipStream_t);
 int ovd_impl_head_unpatchify(const float*, long, const bf16_t*, const bf16_t*, float*, int, int, int, int, int, int,
-                             int, int, int, hipStream_t);
+                             int, int, int, int, hipStream_t);
 int ovd_impl_cfg_unipc_step(const float*, const float*, void*, void*, float*, float*, const float*, float,
                             const int*, int, long, int, hipStream_t);
 int ovd_impl_step_advance(int*, hipStream_t);
@@ -122,9 +122,11 @@ int ovd_head_modulation(const uint16_t* mod, const float* e, float* out, int C, 
 }
 
 int ovd_head_unpatchify(const float* y, int64_t ldy, const uint16_t* W, const uint16_t* bias, float* out, int n_tok,
-                        int C, int Cout, int pt, int ph, int pw, int gf, int gh, int gw, void* stream) {
+                        int C, int Cout, int pt, int ph, int pw, int gf, int gh, int gw, int tok_offset,
+                        void* stream) {
     NONNULL(y); NONNULL(W); NONNULL(out);
-    return ovd_impl_head_unpatchify(y, ldy, W, bias, out, n_tok, C, Cout, pt, ph, pw, gf, gh, gw, ST(stream));
+    return ovd_impl_head_unpatchify(y, ldy, W, bias, out, n_tok, C, Cout, pt, ph, pw, gf, gh, gw, tok_offset,
+                                    ST(stream));
 }
 
 int ovd_cfg_unipc_step(const float* cond, const float* uncond, void* sample, void* last_sample, float* m1, float* m2,

@@ -93,7 +93,8 @@ __global__ void __launch_bounds__(256) head_unpatchify_kernel(const float* __res
                                                               const bf16_t* __restrict__ W,
                                                               const bf16_t* __restrict__ bias,
                                                               float* __restrict__ out, int n_tok, int C, int Cout,
-                                                              int pt, int ph, int pw, int gf, int gh, int gw) {
+                                                              int pt, int ph, int pw, int gf, int gh, int gw,
+                                                              int tok_offset) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + wave) * 32;
     if (row0 >= n_tok) return;
@@ -130,8 +131,9 @@ __global__ void __launch_bounds__(256) head_unpatchify_kernel(const float* __res
         const int r = pq % pw, q = (pq / pw) % ph, p = pq / (pw * ph);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int tok = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-            if (tok >= n_tok) continue;
+            const int lr = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            const int tok = tok_offset + lr;          // y row lr holds token tok_offset + lr
+            if (lr >= n_tok || tok >= gf * gh * gw) continue;
             const int w = tok % gw, h = (tok / gw) % gh, f = tok / (gw * gh);
             const float v = (half ? acc1[reg] : acc0[reg]) + bv;
             out[(((long)c * T_ + (f * pt + p)) * H + (h * ph + q)) * Wd + (w * pw + r)] = v;
@@ -193,13 +195,15 @@ int ovd_impl_head_modulation(const bf16_t* mod, const float* e, float* out, int 
 }
 
 int ovd_impl_head_unpatchify(const float* y, long ldy, const bf16_t* W, const bf16_t* bias, float* out, int n_tok,
-                             int C, int Cout, int pt, int ph, int pw, int gf, int gh, int gw, hipStream_t st) {
+                             int C, int Cout, int pt, int ph, int pw, int gf, int gh, int gw, int tok_offset,
+                             hipStream_t st) {
     OVD_REQUIRE(Cout * pt * ph * pw == 64, "head: out_dim*prod(patch) must be 64, got %d", Cout * pt * ph * pw);
     OVD_REQUIRE(C % 8 == 0 && ldy % 4 == 0, "head: C must be a multiple of 8");
-    OVD_REQUIRE(n_tok == (long)gf * gh * gw, "head: token count %d != grid %dx%dx%d", n_tok, gf, gh, gw);
+    OVD_REQUIRE(n_tok >= 0 && tok_offset >= 0 && tok_offset <= (long)gf * gh * gw,
+                "head: rows %d at token offset %d outside grid %dx%dx%d", n_tok, tok_offset, gf, gh, gw);
     if (n_tok == 0) return 0;
     hipLaunchKernelGGL(head_unpatchify_kernel, dim3(ceil_div(n_tok, 128)), dim3(256), 0, st, y, ldy, W, bias, out,
-                       n_tok, C, Cout, pt, ph, pw, gf, gh, gw);
+                       n_tok, C, Cout, pt, ph, pw, gf, gh, gw, tok_offset);
     OVD_CHECK_LAUNCH("head_unpatchify");
     return 0;
 }

@@ -25,7 +25,7 @@ SIGNATURES = {
     "ovd_gemv_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ovd_modulation_table": [_p, _p, _p, _i, _i, _p],
     "ovd_head_modulation": [_p, _p, _p, _i, _p],
-    "ovd_head_unpatchify": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ovd_head_unpatchify": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_cfg_unipc_step": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
     "ovd_step_advance": [_p, _p],
     "ovd_vae_conv3d_f32": [_p] * 7 + [_i] + [_p] * 4 + [_i] * 14 + [_p],
@@ -210,13 +210,15 @@ def head_modulation(mod, e, out):
     return out
 
 
-def head_unpatchify(y, w, bias, out, grid, patch, out_dim):
+def head_unpatchify(y, w, bias, out, grid, patch, out_dim, tok_offset=0):
+    """y rows 0.. hold tokens tok_offset..; writes those tokens' patches into out [Cout,T,H,W]."""
     M, C, ldy = _rows(y)
     n_tok = grid[0] * grid[1] * grid[2]
-    if n_tok > M or not out.is_contiguous():
-        raise ValueError("head: activation has fewer rows than the grid has tokens")
-    _call("ovd_head_unpatchify", _ptr(y, F32), ldy, _ptr(w, BF16), _ptr(bias, BF16, True), _ptr(out, F32), n_tok, C,
-          out_dim, patch[0], patch[1], patch[2], grid[0], grid[1], grid[2], _stream())
+    rows = max(0, min(M, n_tok - tok_offset))
+    if not out.is_contiguous():
+        raise ValueError("head: out must be contiguous")
+    _call("ovd_head_unpatchify", _ptr(y, F32), ldy, _ptr(w, BF16), _ptr(bias, BF16, True), _ptr(out, F32), rows, C,
+          out_dim, patch[0], patch[1], patch[2], grid[0], grid[1], grid[2], tok_offset, _stream())
     return out
 
 

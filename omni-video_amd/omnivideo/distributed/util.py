@@ -1,0 +1,113 @@
+"""Sequence-parallel process groups and collectives with the reference's names
+(reference: omnivideo/distributed/util.py).  One process per GPU; on MI355X the "nccl"
+backend of torch.distributed is RCCL over xGMI.  The collectives are written against
+`all_to_all_single` / `all_gather_into_tensor` (one contiguous buffer per call instead of
+the reference's per-peer tensor lists, util.py:106-109,143-145), which also run on the
+gloo backend for CPU tests."""
+import torch
+import torch.distributed as dist
+
+_SEQUENCE_PARALLEL_GROUP = None
+_SEQUENCE_PARALLEL_SIZE = 1
+
+
+def init_distributed_group():
+    """reference util.py:9-13"""
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl")
+
+
+def init_sequence_parallel_group(sp_size):
+    """Contiguous rank blocks of size sp_size (reference util.py:16-40)."""
+    if not dist.is_initialized():
+        return None
+    world_size = dist.get_world_size()
+    assert world_size % sp_size == 0
+    rank = dist.get_rank()
+    sp_group = None
+    for i in range(world_size // sp_size):
+        ranks = list(range(i * sp_size, (i + 1) * sp_size))
+        group = dist.new_group(ranks)
+        if rank in ranks:
+            sp_group = group
+    global _SEQUENCE_PARALLEL_GROUP, _SEQUENCE_PARALLEL_SIZE
+    _SEQUENCE_PARALLEL_GROUP = sp_group
+    _SEQUENCE_PARALLEL_SIZE = sp_size
+    return sp_group
+
+
+def init_distributed_groups(sp_size):
+    """Orthogonal data-parallel and sequence-parallel groups (reference util.py:43-66)."""
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl")
+    world_size, rank = dist.get_world_size(), dist.get_rank()
+    sp_group = init_sequence_parallel_group(sp_size)
+    dp_group = None
+    for i in range(sp_size):
+        ranks = [i + j * sp_size for j in range(world_size // sp_size)]
+        group = dist.new_group(ranks)
+        if rank in ranks:
+            dp_group = group
+    return dp_group, sp_group
+
+
+def get_sequence_parallel_group():
+    return _SEQUENCE_PARALLEL_GROUP
+
+
+def get_sequence_parallel_size():
+    return _SEQUENCE_PARALLEL_SIZE
+
+
+def get_sequence_parallel_rank():
+    if _SEQUENCE_PARALLEL_GROUP is None:
+        return 0
+    return dist.get_rank(_SEQUENCE_PARALLEL_GROUP)
+
+
+def get_rank(group=None):
+    if group is None:
+        group = _SEQUENCE_PARALLEL_GROUP
+    if group is None and not dist.is_initialized():
+        return 0
+    return dist.get_rank(group=group)
+
+
+def get_world_size(group=None):
+    if group is None:
+        group = _SEQUENCE_PARALLEL_GROUP
+    if group is None and not dist.is_initialized():
+        return 1
+    return dist.get_world_size(group=group)
+
+
+def all_to_all(x, scatter_dim, gather_dim, group=None, **kwargs):
+    """Scatter x along `scatter_dim`, gather along `gather_dim` (reference util.py:95-121).
+    Inference only: no autograd function is attached."""
+    world = get_world_size(group)
+    if world <= 1:
+        return x
+    if x.size(scatter_dim) % world:
+        raise ValueError(f"dim {scatter_dim} of size {x.size(scatter_dim)} is not divisible by {world} ranks")
+    send = torch.stack([u for u in x.chunk(world, dim=scatter_dim)]).contiguous()
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return torch.cat(list(recv.unbind(0)), dim=gather_dim).contiguous()
+
+
+def all_gather(tensor, group=None):
+    """reference util.py:124-130"""
+    world = get_world_size(group)
+    if world == 1:
+        return [tensor]
+    out = torch.empty(world * tensor.numel(), dtype=tensor.dtype, device=tensor.device)
+    dist.all_gather_into_tensor(out, tensor.contiguous().view(-1), group=group)
+    return list(out.view((world,) + tuple(tensor.shape)).unbind(0))
+
+
+def gather_forward(input, dim, group=None):
+    """All-gather along `dim` (reference util.py:133-161)."""
+    world = get_world_size(group)
+    if world <= 1:
+        return input
+    return torch.cat(all_gather(input, group), dim=dim).contiguous()

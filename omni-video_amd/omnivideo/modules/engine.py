@@ -2,9 +2,10 @@
 
 One `DiTEngine` snapshots a WanModel's weights into the fused layouts the HIP kernels
 want (QKV as one [3C,C] matrix, cross-attention K/V as one [2C,C] matrix), owns every
-workspace buffer for a given (grid, seq_len, branches) shape, and runs the forward as a
-fixed sequence of libomnihip launches on torch's current stream: no allocation, no host
-synchronisation, so a whole sampling step can be captured into a HIP graph.
+workspace buffer for a given (grid, seq_len, branches, sequence-parallel shard) shape, and
+runs the forward as a fixed sequence of libomnihip launches on torch's current stream: no
+allocation, no host synchronisation, so a whole sampling step can be captured into a HIP
+graph.
 
 Compared with the reference's eager module graph (omnivideo/modules/model.py:417-524)
 the engine
@@ -17,10 +18,21 @@ the engine
     (they do not depend on the latents or the timestep; model.py:170-171,480-485
     recompute them in every layer of every forward).
 The arithmetic per element is unchanged, including the reference's bf16 rounding points.
+
+Sequence parallelism (reference: omnivideo/distributed/full_sequence_parallel.py:63-232,
+ulysses.py:8-56): rank r owns the contiguous token rows [r*S/p, (r+1)*S/p); everything
+outside attention is token-local.  Self-attention exchanges q, k, v with ONE all-to-all
+(sequence-gather / head-scatter, the three tensors packed into one message) and the
+attention output with one more.  Cross-attention needs no exchange here: every rank keeps
+the (small, step-invariant) context K/V of all heads and attends its own query rows,
+where the reference shards the context and pays four more all-to-alls per layer
+(full_sequence_parallel.py:221-227).  The head output is combined by one all-reduce of
+the (zero-initialised) latent-sized result.
 """
 import math
 
 import torch
+import torch.distributed as dist
 
 from .. import _hip as H
 
@@ -52,6 +64,22 @@ class ContextCache:
     def __init__(self, kv, text_len):
         self.kv = kv            # [layers, nb, text_len, 2C] bf16: K (normalised) | V
         self.text_len = text_len
+
+
+class TorchGroupComm:
+    """The two collectives the sequence-parallel forward needs, over a torch.distributed
+    group (backend "nccl" = RCCL over xGMI on MI355X)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.size = dist.get_world_size(group=group)
+        self.rank = dist.get_rank(group=group)
+
+    def all_to_all(self, recv, send):
+        dist.all_to_all_single(recv, send, group=self.group)
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, group=self.group)
 
 
 class DiTEngine:
@@ -103,21 +131,31 @@ class DiTEngine:
         self.timing = None
 
     # ------------------------------------------------------------------ workspaces
-    def plan(self, grid, seq_len, nb):
-        key = (tuple(grid), int(seq_len), int(nb))
+    def plan(self, grid, seq_len, nb, comm=None):
+        """Allocates every buffer for `nb` guidance branches over a `seq_len`-row sequence.
+        comm: a communicator (size, rank, all_to_all, all_reduce_sum) for sequence
+        parallelism; this rank then owns rows [rank*seq_len/size, (rank+1)*seq_len/size)."""
+        sp = 1 if comm is None else comm.size
+        rank = 0 if comm is None else comm.rank
+        key = (tuple(grid), int(seq_len), int(nb), sp, rank, id(comm))
         if self._shape == key:
             return
-        dev, C, F = self.device, self.dim, self.ffn_dim
-        M = nb * seq_len
+        dev, C, F, N = self.device, self.dim, self.ffn_dim, self.num_heads
+        if seq_len % sp:
+            raise ValueError(f"seq_len {seq_len} must be a multiple of the sequence-parallel size {sp}")
+        if N % sp:
+            raise ValueError(f"q.num_heads={N} must be divisible by sp_size={sp}")   # reference ulysses.py:33-34
+        S = seq_len // sp
+        M = nb * S
         n_tok = grid[0] * grid[1] * grid[2]
         if n_tok > seq_len:
             raise ValueError(f"seq_len {seq_len} shorter than the {n_tok} latent tokens")
         kpatch = self.in_dim * math.prod(self.patch_size)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
-        self.x = e(nb, seq_len, C, dt=F32)
+        self.x = e(nb, S, C, dt=F32)
         self.h = e(M, C)
-        self.qkv = e(nb, seq_len, 3 * C)
-        self.att = e(nb, seq_len, C)
+        self.qkv = e(nb, S, 3 * C)
+        self.att = e(nb, S, C)
         self.ffn = e(M, F)
         self.y = e(M, C, dt=F32)
         self.rows = e(n_tok, kpatch)
@@ -127,7 +165,16 @@ class DiTEngine:
         self.mod = e(self.num_layers, 6, C, dt=F32)
         self.hmod = e(2, C, dt=F32)
         self.rope = build_rope_table(self.head_dim, max(grid), dev)
+        if sp > 1:
+            Cs = C // sp
+            self.sp_send = e(sp, 3, nb, S, Cs)        # q|k|v of my rows, split by destination head group
+            self.sp_recv = e(sp, 3, nb, S, Cs)        # q|k|v of every rank's rows for my head group
+            self.sp_qkv = e(3, nb, seq_len, Cs)       # full sequence, my heads
+            self.sp_o = e(nb, seq_len, Cs)
+            self.sp_osend = e(sp, nb, S, Cs)
+            self.sp_orecv = e(sp, nb, S, Cs)
         self.grid, self.seq_len, self.nb, self.n_tok = tuple(grid), seq_len, nb, n_tok
+        self.comm, self.sp, self.S, self.row0 = comm, sp, S, rank * S
         self._shape = key
 
     # ------------------------------------------------------------------ context (once per video)
@@ -154,21 +201,51 @@ class DiTEngine:
             H.rmsnorm_rope(kview, L["cnk"], kview, self.head_dim, self.eps)
         return ContextCache(kv, text_len)
 
+    # ------------------------------------------------------------------ attention variants
+    def _self_attention(self, q4, k4, v4, att4):
+        if self.timing is not None:      # profiling hook: events around the dominant kernel
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        H.flash_attn(q4, k4, v4, att4, k_len=self.n_tok)
+        if self.timing is not None:
+            ev[1].record()
+            self.timing.append(ev)
+
+    def _self_attention_sp(self):
+        """Ulysses exchange around the attention kernel (reference ulysses.py:41-55): the q, k
+        and v of this rank's rows go out split by head group in one all-to-all; attention runs
+        over the full sequence for this rank's heads; one all-to-all brings the output back."""
+        C, N, D, nb, S, sp = self.dim, self.num_heads, self.head_dim, self.nb, self.S, self.sp
+        Cs = C // sp
+        # pack: send[j, part, b, s, :] = qkv[b, s, part*C + j*Cs : part*C + (j+1)*Cs]
+        self.sp_send.copy_(self.qkv.view(nb, S, 3, sp, Cs).permute(3, 2, 0, 1, 4))
+        self.comm.all_to_all(self.sp_recv, self.sp_send)
+        # unpack: full[part, b, i*S + s, :] = recv[i, part, b, s, :]
+        self.sp_qkv.view(3, nb, sp, S, Cs).copy_(self.sp_recv.permute(1, 2, 0, 3, 4))
+        q4, k4, v4 = (self.sp_qkv[i].unflatten(2, (N // sp, D)) for i in range(3))
+        self._self_attention(q4, k4, v4, self.sp_o.unflatten(2, (N // sp, D)))
+        # back: osend[j, b, s, :] = o[b, j*S + s, :]  ->  att[b, s, i*Cs:(i+1)*Cs] = orecv[i, b, s, :]
+        self.sp_osend.copy_(self.sp_o.view(nb, sp, S, Cs).permute(1, 0, 2, 3))
+        self.comm.all_to_all(self.sp_orecv, self.sp_osend)
+        self.att.view(nb, S, sp, Cs).copy_(self.sp_orecv.permute(1, 2, 0, 3))
+
     # ------------------------------------------------------------------ forward
-    def forward(self, lat, timesteps, ctx, out, step=0, step_ptr=None, tok_offset=0):
+    def forward(self, lat, timesteps, ctx, out, step=0, step_ptr=None):
         """lat [Cin,T,H,W] (bf16 or fp32, rounded to bf16 on entry as the reference's bf16
-        latents are), timesteps int64 device table, ctx a ContextCache for self.nb branches,
-        out fp32 [nb, Cout, T, H, W].  plan() must have been called for this shape."""
-        C, N, D, nb, S = self.dim, self.num_heads, self.head_dim, self.nb, self.seq_len
+        latents are), timesteps float64 device table, ctx a ContextCache for self.nb branches,
+        out fp32 [nb, Cout, T, H, W].  plan() must have been called for this shape.  Under
+        sequence parallelism every rank passes the same lat / ctx and receives the full out."""
+        C, N, D, nb, S = self.dim, self.num_heads, self.head_dim, self.nb, self.S
         M = nb * S
-        gf, gh, gw = self.grid
-        n_tok = self.n_tok
+        n_tok, row0 = self.n_tok, self.row0
+        n_loc = max(0, min(S, n_tok - row0))          # real (non-padding) tokens among my rows
         if ctx.kv.shape[1] != nb:
             raise ValueError("context cache was built for a different number of branches")
         # patch embedding (model.py:455-464): rows beyond the real tokens stay zero
         H.patchify(lat, self.rows, self.patch_size)
         self.x.zero_()
-        H.gemm(self.rows, self.w_patch, self.x[0, :n_tok], self.b_patch, H.EPI_F32)
+        if n_loc > 0:
+            H.gemm(self.rows[row0:row0 + n_loc], self.w_patch, self.x[0, :n_loc], self.b_patch, H.EPI_F32)
         for b in range(1, nb):
             self.x[b].copy_(self.x[0])
         # timestep embedding, once (model.py:467-476)
@@ -191,17 +268,14 @@ class DiTEngine:
             H.gemm(self.h, L["w_qkv"], qkv2, L["b_qkv"], H.EPI_BF16)
             for sl, nw in ((slice(0, C), L["nq"]), (slice(C, 2 * C), L["nk"])):
                 v_ = qkv2[:, sl]
-                H.rmsnorm_rope(v_, nw, v_, D, self.eps, rope=self.rope, rows_per_sample=S, tok_offset=tok_offset,
+                H.rmsnorm_rope(v_, nw, v_, D, self.eps, rope=self.rope, rows_per_sample=S, tok_offset=row0,
                                n_rope=n_tok, grid=self.grid)
-            if self.timing is not None:      # profiling hook: events around the dominant kernel
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            H.flash_attn(q4, k4, v4, att4, k_len=n_tok)
-            if self.timing is not None:
-                ev[1].record()
-                self.timing.append(ev)
+            if self.sp > 1:
+                self._self_attention_sp()
+            else:
+                self._self_attention(q4, k4, v4, att4)
             H.gemm(att2, L["w_o"], x2, L["b_o"], H.EPI_RESID, gate=mod[2])
-            # cross-attention (model.py:250)
+            # cross-attention (model.py:250): local query rows against the replicated context K/V
             H.layernorm_modulate(x2, self.h, self.eps, weight=L["n3w"], bias=L["n3b"])
             qc = qkv2[:, :C]
             H.gemm(self.h, L["w_cq"], qc, L["b_cq"], H.EPI_BF16)
@@ -216,7 +290,13 @@ class DiTEngine:
         # head + unpatchify (model.py:520-524)
         H.head_modulation(self.head_mod, self.e_vec, self.hmod)
         H.layernorm_modulate(x2, self.y, self.eps, shift=self.hmod[0], scale=self.hmod[1])
+        if self.sp > 1:
+            out.zero_()
         for b in range(nb):
             H.head_unpatchify(self.y[b * S:(b + 1) * S], self.w_head, self.b_head, out[b], self.grid,
-                              self.patch_size, self.out_dim)
+                              self.patch_size, self.out_dim, tok_offset=row0)
+        if self.sp > 1:
+            # every latent element has exactly one owner rank: the sum is an exact gather
+            # (the reference all-gathers the head output rows, full_sequence_parallel.py:163)
+            self.comm.all_reduce_sum(out)
         return out

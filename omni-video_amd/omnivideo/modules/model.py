@@ -290,6 +290,10 @@ class WanModel(nn.Module):
     def forward(self, x, t, context, seq_len, y=None):
         """x: list of [Cin,F,H,W]; t: [B]; context: list of [L,text_dim]; returns a list of
         fp32 [Cout,F,H,W] (reference model.py:417-524)."""
+        return self._forward_impl(x, t, context, seq_len, y=y)
+
+    def _forward_impl(self, x, t, context, seq_len, y=None, comm=None):
+        """comm: sequence-parallel communicator (distributed/full_sequence_parallel.py)."""
         if self.model_type == "i2v":
             assert y is not None
         if y is not None:
@@ -305,7 +309,7 @@ class WanModel(nn.Module):
             pt, ph, pw = self.patch_size
             grid = (u.shape[1] // pt, u.shape[2] // ph, u.shape[3] // pw)
             assert grid[0] * grid[1] * grid[2] <= seq_len
-            eng.plan(grid, seq_len, 1)
+            eng.plan(grid, seq_len, 1, comm=comm)
             cache = self.context_cache([context[i]])
             out = torch.empty(1, self.out_dim, grid[0] * pt, grid[1] * ph, grid[2] * pw, dtype=F32,
                               device=eng.device)

@@ -37,7 +37,7 @@ class DenoiseLoop:
     for one latent, as graph-replayable device work."""
 
     def __init__(self, models_by_step, lat, ctx_pairs, seq_len, scheduler, guide_scale, use_graph=True,
-                 tok_offset=0):
+                 comm=None):
         """models_by_step: list (one per step) of the UnifiedWan model serving that step;
         ctx_pairs: {id(model): (mixed_cond, mixed_uncond)} context tensors [n, text_dim]."""
         self.lat = lat
@@ -58,7 +58,7 @@ class DenoiseLoop:
             if id(m) in self.engines:
                 continue
             eng = m.wan_model.engine()
-            eng.plan(self.grid, seq_len, 2)
+            eng.plan(self.grid, seq_len, 2, comm=comm)
             self.engines[id(m)] = eng
             self.caches[id(m)] = eng.encode_context(list(ctx_pairs[id(m)]), m.wan_model.text_len)
 
@@ -112,6 +112,8 @@ class OmniVideoX2XUnified:
         self._init_sequence_parallel(use_usp, sp_size)
         self._build_models(wan_config, checkpoint_dir, vlm_in_dim, use_visual_context_adapter,
                            visual_context_adapter_patch_size, max_context_len)
+        if self.use_usp:
+            self._apply_usp({id(m): m for m in (self.high_noise_model, self.low_noise_model)}.values())
         self.sample_neg_prompt = config.sample_neg_prompt_en
         self.special_tokens = self._load_special_tokens(checkpoint_dir)
         self.use_graph = True
@@ -134,8 +136,24 @@ class OmniVideoX2XUnified:
             self.sp_group = init_sequence_parallel_group(self.config.get("sp_size", 1) if sp_size is None else sp_size)
             self.sp_size = get_sequence_parallel_size()
             self.sp_rank = get_rank(self.sp_group)
+            from .modules.engine import TorchGroupComm
+            self.sp_comm = TorchGroupComm(self.sp_group) if self.sp_size > 1 else None
         else:
-            self.sp_group, self.sp_size, self.sp_rank = None, 1, 0
+            self.sp_group, self.sp_size, self.sp_rank, self.sp_comm = None, 1, 0, None
+
+    def _apply_usp(self, models):
+        """Binds the sequence-parallel forwards as the reference does (x2x_gen_unified.py:172-182)."""
+        import types
+        from .distributed.full_sequence_parallel import sp_attn_forward, sp_cross_attn_forward, sp_dit_forward
+        for m in models:
+            m.wan_model.sp_group = self.sp_group
+            for block in m.wan_model.blocks:
+                block.self_attn.sp_group = self.sp_group
+                block.cross_attn.sp_group = self.sp_group
+                block.sp_group = self.sp_group
+                block.self_attn.forward = types.MethodType(sp_attn_forward, block.self_attn)
+                block.cross_attn.forward = types.MethodType(sp_cross_attn_forward, block.cross_attn)
+            m.wan_model.forward = types.MethodType(sp_dit_forward, m.wan_model)
 
     def _new_model(self, wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len):
         if wan_config is None:
@@ -247,7 +265,9 @@ class OmniVideoX2XUnified:
                     c = m.build_mixed_context(1, context, ar_vision_input, visual_emb, self.special_tokens)[0]
                     u = m.build_mixed_context(1, context_null, ar_null, visual_emb, self.special_tokens)[0]
                     pairs[id(m)] = (c, u)
-            loop = DenoiseLoop(models, lat, pairs, seq_len, sched, guide_scale, use_graph=self.use_graph)
+            # collectives are not captured: with sequence parallelism the step runs eagerly
+            loop = DenoiseLoop(models, lat, pairs, seq_len, sched, guide_scale,
+                               use_graph=self.use_graph and self.sp_comm is None, comm=self.sp_comm)
             lat = loop.run()
             if dist.is_initialized():
                 dist.barrier()

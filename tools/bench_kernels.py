@@ -55,10 +55,36 @@ def gemm(M, N, K, epi=0):
     print(f"gemm M{M} N{N} K{K} epi{epi}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
+def vae(latent=(16, 13, 60, 104), encode=False):
+    """Full-width (dim 96) VAE decode (and encode) of one cfg2-sized latent, random weights."""
+    import time
+    from omnivideo.modules.vae2_1 import Wan2_1_VAE
+    with torch.device("cuda"):
+        v = Wan2_1_VAE(z_dim=16, vae_pth=None, device="cuda")
+    z = torch.randn(*latent, device="cuda")
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        x = v.decode([z])[0]
+        torch.cuda.synchronize()
+        print(f"vae decode {latent} -> {tuple(x.shape)}: {time.time() - t0:.3f} s", flush=True)
+    if encode:
+        for it in range(2):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            z2 = v.encode([x])[0]
+            torch.cuda.synchronize()
+            print(f"vae encode {tuple(x.shape)} -> {tuple(z2.shape)}: {time.time() - t0:.3f} s", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["attn", "gemm"])
     args = ap.parse_args()
+    if "vae" in args.what:
+        vae(encode=True)
+    if "vae_small" in args.what:
+        vae((16, 3, 30, 52), encode=True)
     if "attn" in args.what:
         attn(1, 1024, 1024, 2, 1000, check=True)
         attn(2, 20280, 20280, 12)
