@@ -27,12 +27,20 @@ def timeit(fn, iters=10, warm=2):
     return a.elapsed_time(b) / iters
 
 
-def attn(B, Lq, Lk, N, k_len=None, check=False):
+def attn(B, Lq, Lk, N, k_len=None, check=False, strided_q=False, fused_kv=False, same_rows=0):
     D = 128
-    q = torch.randn(B, Lq, N, D, device="cuda").to(BF16)
+    if strided_q:      # q addressed inside a fused [B, Lq, 3*N*D] projection buffer
+        q = torch.randn(B, Lq, 3 * N * D, device="cuda").to(BF16)[:, :, :N * D].unflatten(2, (N, D))
+    else:
+        q = torch.randn(B, Lq, N, D, device="cuda").to(BF16)
     k = torch.randn(B, Lk, N, D, device="cuda").to(BF16)
     v = torch.randn(B, Lk, N, D, device="cuda").to(BF16)
-    o = torch.empty_like(q)
+    if fused_kv:       # k | v halves of one [B, Lk, 2*N*D] buffer (the cached cross-attention K/V)
+        kv = torch.randn(B, Lk, 2 * N * D, device="cuda").to(BF16)
+        if same_rows:
+            kv[:, same_rows:] = kv[:, same_rows:same_rows + 1]
+        k, v = kv[:, :, :N * D].unflatten(2, (N, D)), kv[:, :, N * D:].unflatten(2, (N, D))
+    o = torch.empty(B, Lq, N, D, device="cuda", dtype=BF16)
     ms = timeit(lambda: H.flash_attn(q, k, v, o, k_len=k_len))
     fl = 4.0 * B * N * Lq * (k_len or Lk) * D
     msg = f"attn B{B} Lq{Lq} Lk{Lk} N{N}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s"
@@ -89,6 +97,12 @@ if __name__ == "__main__":
         attn(1, 1024, 1024, 2, 1000, check=True)
         attn(2, 20280, 20280, 12)
         attn(2, 20280, 6144, 12)
+    if "xattn" in args.what:
+        attn(2, 20280, 512, 12)
+        attn(2, 20280, 512, 12, strided_q=True)
+        attn(2, 20280, 64, 12, strided_q=True)
+        attn(2, 20280, 512, 12, strided_q=True, fused_kv=True)
+        attn(2, 20280, 512, 12, strided_q=True, fused_kv=True, same_rows=20)
     if "gemm" in args.what:
         M = 40560
         gemm(M, 4608, 1536, 0)      # fused QKV
