@@ -260,12 +260,319 @@ attn_fwd_body(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Two-tile software pipeline: while the matrix pipe computes S^T of tile t+1, the vector
+// pipe finishes the softmax of tile t; the row maximum of tile t+1 is folded in between
+// the P V products of tile t.  Scores of two tiles are live (named pairs, swapped by call
+// order).  LDS holds K(t+1) and V(t) during step t; K(t+2) and V(t+1) stream in under it.
+
+// raw (unscaled) maximum of this lane's 32 scores
+__device__ __forceinline__ float lane_max32(const f32x16& a, const f32x16& b) {
+    float mx = max3(a[0], a[1], a[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = max3(mx, a[r], a[r + 1]);
+    mx = max3(mx, a[15], b[0]);
+#pragma unroll
+    for (int r = 1; r < 15; r += 2) mx = max3(mx, b[r], b[r + 1]);
+    return __builtin_fmaxf(mx, b[15]);
+}
+
+template <bool MASK>
+__device__ __forceinline__ void mask_scores(f32x16& s0, f32x16& s1, int key0, int k_len, int hi) {
+    if (MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= k_len) s0[r] = -1e30f;
+            if (key + 32 >= k_len) s1[r] = -1e30f;
+        }
+    }
+}
+
+// Streams one operand (K or V) HBM -> LDS, one 64-row tile per call: per-lane byte offset of
+// this lane's row in the next tile (pass 0), advanced by a tile per call and clamped to the
+// operand's last row (tiles that reach past it only feed masked keys).
+struct Stream {
+    const char* base;    // (batch, head) base of the operand
+    unsigned row;        // byte offset of this lane's row of the next tile to stage (pass 0)
+    unsigned chunk;      // byte offset of this lane's (swizzled) 16-byte chunk inside the row
+    unsigned last;       // byte offset of the operand's last row
+    unsigned pass;       // bytes between the rows of consecutive passes (4 * NW rows)
+    unsigned tile;       // bytes per 64-row tile
+};
+
+template <int NW>
+__device__ __forceinline__ void stage_next(Stream& s, char* dst_wave) {
+#pragma unroll
+    for (int i = 0; i < 16 / NW; ++i) {
+        const unsigned ro = min(s.row + i * s.pass, s.last);
+        __builtin_amdgcn_global_load_lds(s.base + ro + s.chunk, (lds_ptr)(dst_wave + i * NW * 1024), 16, 0, 0);
+    }
+    s.row += s.tile;
+}
+
+// c0/c1: scores of the current tile; mx = their row maximum (scaled, whole wave), need = some
+// row's maximum outgrew the running one.  n0/n1 receive the scores of the next tile (HAS_NEXT),
+// read from sk_next; V of the current tile is in sv_cur.  The K tile after next and the next
+// V tile are put in flight from inside the first two k-steps.
+template <int NW, bool HAS_NEXT, bool MASK_NEXT>
+__device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)[8], float& m_c, float& l_run,
+                                          const f32x16& c0, const f32x16& c1, f32x16& n0, f32x16& n1,
+                                          float& mx, bool& need, const char* sk_next, const char* sv_cur,
+                                          Stream& ks_, char* k_dst, Stream& vs_, char* v_dst, int key0_next,
+                                          int k_len, float scale_log2, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    if (need) {
+        const float m_new = __builtin_fmaxf(m_c, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_c - m_new);
+        m_c = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o_acc[i][j] *= alpha;
+    }
+    // ---- S^T of the next tile (MFMA) beside exp / sum / pack of the current one (VALU)
+    if (HAS_NEXT) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) n0[j] = n1[j] = 0.f;
+    }
+    float rs0 = 0.f, rs1 = 0.f;
+    uint32_t pw[16];     // packed bf16 pairs of P: word i = scores 2i, 2i+1 (score i<16 -> c0[i], else c1[i-16])
+    // exp / sum / pack of two adjacent scores; the empty asm pins the result inside the
+    // scheduling region it is written in (pure arithmetic would otherwise sink to its use)
+#define SOFTMAX_PAIR(i)                                                                            \
+    do {                                                                                           \
+        const f32x16& c_ = (i) < 8 ? c0 : c1;                                                      \
+        const int r_ = ((i) & 7) * 2;                                                              \
+        const float pa_ = __builtin_amdgcn_exp2f(__builtin_fmaf(c_[r_], scale_log2, -m_c));        \
+        const float pb_ = __builtin_amdgcn_exp2f(__builtin_fmaf(c_[r_ + 1], scale_log2, -m_c));    \
+        rs0 += pa_;                                                                                \
+        rs1 += pb_;                                                                                \
+        pw[i] = pack_bf2(pa_, pb_);                                                                \
+        asm volatile("" : "+v"(pw[i]), "+v"(rs0), "+v"(rs1));                                      \
+    } while (0)
+    const int g = lane >> 4, i16 = lane & 15, qd = i16 >> 2, pp = i16 & 3;
+    bf16x8 vf[2][4];
+#define READ_V(st, dst)                                                                            \
+    _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                             \
+        const int krow = 16 * (st) + 4 * (g >> 1) + qd;                                            \
+        const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);                                        \
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                              \
+            (lds_b4_ptr)(sv_cur + v_off(krow, chunk) + 8 * (pp & 1)));                             \
+        const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                             \
+            (lds_b4_ptr)(sv_cur + v_off(krow + 8, chunk) + 8 * (pp & 1)));                         \
+        const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi4);     \
+        dst[db] = __builtin_bit_cast(bf16x8, make_uint4(lo2.x, lo2.y, hi2.x, hi2.y));              \
+    }
+    // K fragments are fetched one k-step ahead; the scheduling fences keep each k-step's
+    // {2 LDS reads, 2 MFMAs, its share of the softmax} together so that register life times
+    // stay short and the vector work sits in the MFMA shadows.  24 of the 32 scores are
+    // finished here (4 / 2 per k-step), the last 8 beside the first P V products.
+    bf16x8 kf[2][2];
+    if (HAS_NEXT) {
+        kf[0][0] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(l31, hi));
+        kf[0][1] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(32 + l31, hi));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (HAS_NEXT) {
+            if (ks < 7) {
+                kf[(ks + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(l31, 2 * ks + 2 + hi));
+                kf[(ks + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(32 + l31, 2 * ks + 2 + hi));
+            }
+            n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][0], qf[ks], n0, 0, 0, 0);
+            n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][1], qf[ks], n1, 0, 0, 0);
+        }
+        const int pi = 3 * (ks >> 1) + 2 * (ks & 1);      // first pair of this k-step: 0,2,3,5,6,8,9,11
+        SOFTMAX_PAIR(pi);
+        if (!(ks & 1)) SOFTMAX_PAIR(pi + 1);
+        if (ks == 0) stage_next<NW>(ks_, k_dst);
+        if (ks == 1) stage_next<NW>(vs_, v_dst);
+        if (ks == 7) READ_V(0, vf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (HAS_NEXT) mask_scores<MASK_NEXT>(n0, n1, key0_next, k_len, hi);
+
+    // ---- O^T += V^T P^T of the current tile; beside it the last 8 scores' softmax, then the
+    // next tile's lane maximum
+    float nmx = -3.0e38f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        if (st < 3) READ_V(st + 1, vf[(st + 1) & 1]);
+        const bf16x8 pfrag =
+            __builtin_bit_cast(bf16x8, make_uint4(pw[4 * st], pw[4 * st + 1], pw[4 * st + 2], pw[4 * st + 3]));
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+            o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st & 1][db], pfrag, o_acc[db], 0, 0, 0);
+        if (st < 2) {
+            SOFTMAX_PAIR(12 + 2 * st);
+            SOFTMAX_PAIR(13 + 2 * st);
+        } else if (HAS_NEXT) {
+            const f32x16& n = st == 2 ? n0 : n1;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) nmx = max3(nmx, n[r], n[r + 1]);
+            asm volatile("" : "+v"(nmx));
+            if (st == 3) {
+                mx = half_max(nmx) * scale_log2;
+                need = __any(mx > m_c + RESCALE_THR);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    l_run += rs0 + rs1;
+#undef READ_V
+#undef SOFTMAX_PAIR
+}
+
+template <int NW>
+__device__ __forceinline__ void
+attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+              bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,
+              long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2] | V[2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+
+    const bf16_t* Qb = Q + b * q_bs + (long)head * HD;
+    const bf16_t* Kb = K + b * k_bs + (long)head * HD;
+    const bf16_t* Vb = V + b * v_bs + (long)head * HD;
+
+    bf16x8 qf[8];
+    {
+        int qr = q0 + l31;
+        qr = qr < Lq ? qr : Lq - 1;
+        const bf16_t* qp = Qb + (long)qr * q_ld + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+    f32x16 o_acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o_acc[i][j] = 0.f;
+    float m_c = -1e30f, l_run = 0.f;
+    const int nt = (k_len + BKV - 1) / BKV;
+    const bool partial = nt * BKV > k_len;
+
+    // staging pass i of wave w covers tile rows 4*(i*NW + w) .. +3 (one wave instruction = 4 rows,
+    // lane-linear in LDS); the XOR swizzle of k_off / v_off is applied to the SOURCE chunk
+    Stream kst, vst;
+    {
+        const int r = wave * 4 + (lane >> 4), p = lane & 15;
+        kst.base = reinterpret_cast<const char*>(Kb);
+        vst.base = reinterpret_cast<const char*>(Vb);
+        kst.row = (unsigned)r * (unsigned)k_ld * 2u;
+        vst.row = (unsigned)r * (unsigned)v_ld * 2u;
+        kst.chunk = (unsigned)((p ^ (r & 15)) << 4);
+        vst.chunk = (unsigned)((p ^ ((r & 3) << 2)) << 4);
+        kst.last = (unsigned)(Lk - 1) * (unsigned)k_ld * 2u;
+        vst.last = (unsigned)(Lk - 1) * (unsigned)v_ld * 2u;
+        kst.pass = 4u * NW * (unsigned)k_ld * 2u;
+        vst.pass = 4u * NW * (unsigned)v_ld * 2u;
+        kst.tile = (unsigned)BKV * (unsigned)k_ld * 2u;
+        vst.tile = (unsigned)BKV * (unsigned)v_ld * 2u;
+    }
+    char* const wave_lds = smem + wave * 1024;
+    stage_next<NW>(kst, wave_lds);                                   // K(0) -> K buffer 0
+    stage_next<NW>(vst, wave_lds + 2 * KV_TILE_BYTES);               // V(0) -> V buffer 0
+    stage_next<NW>(kst, wave_lds + KV_TILE_BYTES);                   // K(1) -> K buffer 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 a0, a1, b0, b1;
+    float mx;
+    bool need;
+    {   // scores of tile 0
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a0[j] = a1[j] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(smem + k_off(l31, 2 * ks + hi));
+            const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(smem + k_off(32 + l31, 2 * ks + hi));
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], a1, 0, 0, 0);
+        }
+        if (nt == 1 && partial) mask_scores<true>(a0, a1, 0, k_len, hi);
+        mx = half_max(lane_max32(a0, a1)) * scale_log2;
+        need = __any(mx > m_c + RESCALE_THR);
+    }
+    __syncthreads();    // every wave is done with K(0) before K(2) overwrites it
+
+    // one step: cur = (C0, C1) holds tile t; (N0, N1) receives tile t + 1; K(t + 2) streams into
+    // the K buffer tile t used, V(t + 1) into the V buffer tile t - 1 used
+#define PIPE_STEP(HAS_NEXT, MASK_NEXT, C0, C1, N0, N1, t)                                                \
+    do {                                                                                                 \
+        const int t_ = (t);                                                                              \
+        pipe_step<NW, HAS_NEXT, MASK_NEXT>(o_acc, qf, m_c, l_run, C0, C1, N0, N1, mx, need,              \
+                                           smem + ((t_ + 1) & 1) * KV_TILE_BYTES,                        \
+                                           smem + (2 + (t_ & 1)) * KV_TILE_BYTES, kst,                   \
+                                           wave_lds + (t_ & 1) * KV_TILE_BYTES, vst,                     \
+                                           wave_lds + (2 + ((t_ + 1) & 1)) * KV_TILE_BYTES,              \
+                                           (t_ + 1) * BKV, k_len, scale_log2, lane);                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+        __syncthreads();                                                                                 \
+    } while (0)
+
+    // steps whose next tile exists and needs no mask run in the loop (one code path, two
+    // roles); a masked next tile and the last tile are peeled behind it
+    const int n_pipe = partial ? (nt >= 2 ? nt - 2 : 0) : nt - 1;
+    int t = 0;
+    for (; t + 1 < n_pipe; t += 2) {
+        PIPE_STEP(true, false, a0, a1, b0, b1, t);
+        PIPE_STEP(true, false, b0, b1, a0, a1, t + 1);
+    }
+    if (t < n_pipe) {
+        PIPE_STEP(true, false, a0, a1, b0, b1, t);
+        a0 = b0;
+        a1 = b1;
+        ++t;
+    }
+    if (partial && nt >= 2) {
+        PIPE_STEP(true, true, a0, a1, b0, b1, t);
+        a0 = b0;
+        a1 = b1;
+        ++t;
+    }
+    PIPE_STEP(false, false, a0, a1, b0, b1, t);
+#undef PIPE_STEP
+
+    const float inv = 1.0f / half_sum(l_run);
+    const int qr = q0 + l31;
+    if (qr < Lq) {
+        bf16_t* op = O + b * o_bs + (long)qr * o_ld + (long)head * HD + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(o_acc[db][4 * g4 + 0] * inv, o_acc[db][4 * g4 + 1] * inv);
+                w.y = pack_bf2(o_acc[db][4 * g4 + 2] * inv, o_acc[db][4 * g4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + db * 32 + 8 * g4) = w;
+            }
+    }
+}
+
 #define ATTN_KERNEL(NW)                                                                                  \
     __global__ void __launch_bounds__(64 * NW, 2) attn_fwd_kernel_w##NW(                                 \
         const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,       \
         bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,   \
         long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2) {                                  \
         attn_fwd_body<NW>(Q, K, V, O, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs,     \
+                          scale_log2);                                                                   \
+    }
+ATTN_KERNEL(4)
+ATTN_KERNEL(8)
+#undef ATTN_KERNEL
+#define ATTN_KERNEL(NW)                                                                                  \
+    __global__ void __launch_bounds__(64 * NW, 2) attn_pipe_kernel_w##NW(                                \
+        const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,       \
+        bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,   \
+        long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2) {                                  \
+        attn_fwd_pipe<NW>(Q, K, V, O, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs,     \
                           scale_log2);                                                                   \
     }
 ATTN_KERNEL(4)
@@ -288,6 +595,8 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
     OVD_REQUIRE(q_ld >= (long)N * D && k_ld >= (long)N * D && v_ld >= (long)N * D && o_ld >= (long)N * D,
                 "attention: token stride shorter than N*D");
     OVD_REQUIRE(softmax_scale > 0.f, "attention: softmax_scale must be positive");
+    OVD_REQUIRE(((long)Lk + 4 * BKV) * (k_ld > v_ld ? k_ld : v_ld) * 2 < (1L << 32),
+                "attention: one (batch, head) slab of K/V must span less than 4 GiB (Lk=%d)", Lk);
     const size_t lds = 4 * KV_TILE_BYTES;
     const float scale_log2 = softmax_scale * 1.4426950408889634f;
     static int variant = -1;
@@ -295,20 +604,29 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
         const char* e = getenv("OVD_ATTN_WAVES");
         variant = (e && atoi(e) == 8) ? 8 : 4;
     }
-#define ATTN_CASE(NW)                                                                                      \
+    static int pipe = -1;
+    if (pipe < 0) {
+        const char* e = getenv("OVD_ATTN_PIPE");
+        pipe = e ? atoi(e) : 1;
+    }
+#define ATTN_CASE(KERNEL, NW)                                                                              \
     {                                                                                                      \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel_w##NW),                   \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
                 OVD_FAIL("attention: cannot reserve %zu bytes of LDS", lds);                                \
             attr_set = true;                                                                               \
         }                                                                                                  \
         dim3 grid(ceil_div(Lq, 32 * NW), N, B), blk(64 * NW);                                              \
-        hipLaunchKernelGGL(attn_fwd_kernel_w##NW, grid, blk, lds, st, q, k, v, out, Lq, Lk, k_len, q_ld,   \
+        hipLaunchKernelGGL(KERNEL, grid, blk, lds, st, q, k, v, out, Lq, Lk, k_len, q_ld,   \
                            k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs, scale_log2);                          \
     }
-    if (variant == 8) ATTN_CASE(8) else ATTN_CASE(4)
+    if (pipe) {
+        if (variant == 8) ATTN_CASE(attn_pipe_kernel_w8, 8) else ATTN_CASE(attn_pipe_kernel_w4, 4)
+    } else {
+        if (variant == 8) ATTN_CASE(attn_fwd_kernel_w8, 8) else ATTN_CASE(attn_fwd_kernel_w4, 4)
+    }
 #undef ATTN_CASE
     OVD_CHECK_LAUNCH("attn_fwd");
     return 0;
