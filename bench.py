@@ -182,7 +182,7 @@ def main():
             flops_launch = 4.0 * L * L * cfg["dim"] * 2            # batch of 2 guidance branches
             avg_ms = sum(ms) / len(ms)
             ach = flops_launch / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "attn_fwd_kernel (self-attention)", "achieved": round(ach, 1),
+            roof = {"bound": "mfma", "kernel": "attn_pipe_kernel_w8 (self-attention)", "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": None, "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4),
                     "flop_per_launch": flops_launch}
