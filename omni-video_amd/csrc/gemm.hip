@@ -163,6 +163,10 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const bf16_t* __restrict
 // Reference call sites: nn.Linear under bf16 autocast throughout
 // omnivideo/modules/model.py (q/k/v/o :118-121, ffn :211-213, text_embedding :386-388)
 // and the gated residual adds of WanAttentionBlock.forward (:245-254).
+bool ovd_gemm256_applicable(long lda, long ldw, int M, int N, int K);
+int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, const bf16_t* bias, void* out,
+                          long ldo, const float* gate, int M, int N, int K, int epilogue, hipStream_t st);
+
 int ovd_impl_gemm_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, const bf16_t* bias, void* out,
                        long ldo, const float* gate, int M, int N, int K, int epilogue, hipStream_t st) {
     OVD_REQUIRE(K > 0 && K % BK == 0, "gemm: K=%d must be a positive multiple of %d", K, BK);
@@ -172,6 +176,14 @@ int ovd_impl_gemm_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, con
     OVD_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm: unknown epilogue %d", epilogue);
     OVD_REQUIRE(gate == nullptr || epilogue == EPI_RESID, "gemm: gate only applies to the residual epilogue");
     if (M == 0) return 0;
+    // large shapes go to the 256 x 256 deep-pipelined kernel (OVD_GEMM256=0 disables: tuning aid)
+    static int use256 = -1;
+    if (use256 < 0) {
+        const char* e = getenv("OVD_GEMM256");
+        use256 = e ? atoi(e) : 1;
+    }
+    if (use256 && ovd_gemm256_applicable(lda, ldw, M, N, K))
+        return ovd_impl_gemm256_bf16(A, lda, W, ldw, bias, out, ldo, gate, M, N, K, epilogue, st);
     const int tiles_m = ceil_div(M, BM), tiles_n = N / BN;
     dim3 grid(tiles_m * tiles_n), blk(256);
     const size_t lds = 4 * TILE_BYTES;

@@ -1,0 +1,250 @@
+// Large-shape bf16 GEMM with the epilogues of gemm.hip:
+//   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] + bias[n] ),  A [M,K], W [N,K] (nn.Linear).
+//
+// One workgroup = 8 waves = a 256 x 256 output tile; wave (wr, wc) = (w >> 2, w & 3) owns
+// 128 rows x 64 columns = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 (128 accumulator
+// registers), computed transposed (weight rows on the MFMA M axis) so that a lane ends up
+// with 4 consecutive output columns of one row.
+//
+// Operands stream HBM -> LDS with 16-byte global_load_lds into a ring of 4 K-tiles of 32
+// (per K-tile: A part 256 rows x 64 B, W part 256 rows x 64 B = 32 KiB; 128 KiB in all,
+// one workgroup per CU).  A K-tile is consumed in two phases of 16 MFMAs per wave (rows
+// 0-63 then 64-127 of the wave's 128); every phase also puts one 16-KiB part of the
+// K-tile three ahead in flight, so a part has four to five phases to land and the loop
+// never drains the vector-memory counter: one counted s_waitcnt vmcnt(8) per K-tile.
+//
+// The two waves that share a SIMD (w and w + 4) run half a phase apart: waves 4-7 execute
+// one extra s_barrier before the loop (waves 0-3 one after it), so that one of them issues
+// its LDS reads and DMA while the other one feeds the matrix pipe.
+//
+// LDS rows are 64 B = 4 chunks of 16 B; chunk c of row r is stored at chunk position
+// c ^ h((r >> 2) & 3), h = {0,3,2,1}, which makes every 16-lane group of a ds_read_b128
+// fragment read hit 16 distinct bank slots.  The swizzle is applied on the SOURCE address
+// of the DMA (its LDS image is lane-linear) and again on the read address.
+//
+// Hazards the schedule is built around:
+//   * a part is re-staged two phases after its last read (the other half of the waves
+//     reads it half a phase later), and read one phase after the wait that retires it;
+//   * raw s_barrier + explicit lgkmcnt waits only inside the loop: a __syncthreads()
+//     would drain the DMA queue;
+//   * no ordinary global load while DMA is in flight (bias / gate are read in the epilogue).
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 32, NSTAGE = 4;
+constexpr int PART = 256 * TK * 2;      // 16 KiB: one operand of one K-tile
+constexpr int STAGE = 2 * PART;         // A part | W part
+
+enum Epi { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3 };
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+struct Src {
+    const char* base;      // operand base advanced to the K-tile being staged (uniform)
+    unsigned off[2];       // this lane's byte offsets (clamped row * ld + swizzled chunk) for its two rows
+};
+
+__device__ __forceinline__ void stage_part(const Src& s, long kbyte, char* dst_wave) {
+    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[0], (lds_ptr)dst_wave, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[1], (lds_ptr)(dst_wave + 8 * 1024), 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// One K-tile (two phases).  STAGE_NEXT: put K-tile kt + 3 in flight; VMCNT: DMA instructions
+// that may stay outstanding after this tile's wait (8 in the steady state).
+template <bool STAGE_NEXT, int VMCNT>
+__device__ __forceinline__ void k_tile(f32x4 (&acc)[4][8], const char* smem, int kt, const Src& sa, const Src& sw,
+                                       int lane_off, int a_rd, int w_rd, int wave) {
+    const char* st = smem + (kt & (NSTAGE - 1)) * STAGE;
+    char* nx = const_cast<char*>(smem) + ((kt + 3) & (NSTAGE - 1)) * STAGE + wave * 1024;
+    const long kb = (long)(kt + 3) * TK * 2;
+    bf16x8 wf[4], af[4];
+    // ---- phase 0: W fragments + rows 0-63; stage the W part
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[t] = lds_frag(st + PART + w_rd + t * 1024 + lane_off);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) af[t] = lds_frag(st + a_rd + t * 1024 + lane_off);
+    if (STAGE_NEXT) stage_part(sw, kb, nx + PART);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: rows 64-127; stage the A part; retire the K-tile read next
+#pragma unroll
+    for (int t = 0; t < 4; ++t) af[t] = lds_frag(st + a_rd + (4 + t) * 1024 + lane_off);
+    if (STAGE_NEXT) stage_part(sa, kb, nx);
+    if (VMCNT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (VMCNT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (VMCNT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            acc[nt][4 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][4 + mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
+               const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
+               int M, int N, int K, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // blocks that share an XCD (same id mod 8) get one contiguous chunk of the tile grid,
+    // walked in groups of 4 tile-rows so that A and W tiles are re-used out of that XCD's L2
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group;
+    const int first_m = grp * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + (bid % per_group) % gsz;
+    const int tn = (bid % per_group) / gsz;
+    const int row0 = tm * TM, col0 = tn * TN;
+
+    // staging: wave w, instruction i covers part rows (i*8 + w)*16 .. +15, 4 lanes per row
+    Src sa, sw;
+    sa.base = reinterpret_cast<const char*>(A);
+    sw.base = reinterpret_cast<const char*>(W);
+    {
+        const int c = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (i * 8 + wave) * 16 + (lane >> 2);
+            const int ar = min(row0 + r, M - 1);
+            sa.off[i] = (unsigned)ar * (unsigned)lda * 2u + (unsigned)c * 16u;
+            sw.off[i] = (unsigned)(col0 + r) * (unsigned)ldw * 2u + (unsigned)c * 16u;
+        }
+    }
+    // fragment reads: lane (r = lane & 15, q = lane >> 4) reads chunk q of row r of a 16-row block
+    const int lane_off = (lane & 15) * 64 + (((lane >> 4) ^ ((4 - ((lane & 15) >> 2)) & 3)) << 4);
+    const int a_rd = wr * 8192, w_rd = wc * 4096;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / TK;      // >= 3 (checked on the host)
+    char* const wdst = smem + wave * 1024;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        stage_part(sw, (long)t * TK * 2, wdst + t * STAGE + PART);
+        stage_part(sa, (long)t * TK * 2, wdst + t * STAGE);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // K-tile 0 landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: half a phase behind
+
+    int kt = 0;
+    for (; kt < nk - 3; ++kt) k_tile<true, 8>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
+    k_tile<false, 4>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
+    k_tile<false, 0>(acc, smem, kt + 1, sa, sw, lane_off, a_rd, w_rd, wave);
+    k_tile<false, -1>(acc, smem, kt + 2, sa, sw, lane_off, a_rd, w_rd, wave);
+    if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
+
+    // epilogue: lane holds out[m][n..n+3], m = row0 + wr*128 + mt*16 + fr, n = col0 + wc*64 + nt*16 + fq*4
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = col0 + wc * 64 + nt * 16 + fq * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const uint2 bp = *reinterpret_cast<const uint2*>(bias + n);
+            bv[0] = bf2f(bp.x & 0xffff);
+            bv[1] = bf2f(bp.x >> 16);
+            bv[2] = bf2f(bp.y & 0xffff);
+            bv[3] = bf2f(bp.y >> 16);
+        }
+        float gv[4] = {1.f, 1.f, 1.f, 1.f};
+        if (EPI == EPI_RESID && gate) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gate + n);
+            gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = row0 + wr * 128 + mt * 16 + fr;
+            if (m >= M) continue;
+            float y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = acc[nt][mt][j] + bv[j];
+            if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+                if (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(round_bf(y[j]));
+                }
+                uint2 o;
+                o.x = pack_bf2(y[0], y[1]);
+                o.y = pack_bf2(y[2], y[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)m * ldo + n) = o;
+            } else if (EPI == EPI_F32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)m * ldo + n) =
+                    make_float4(round_bf(y[0]), round_bf(y[1]), round_bf(y[2]), round_bf(y[3]));
+            } else {
+                float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)m * ldo + n);
+                float4 x = *p;
+                x.x += round_bf(y[0]) * gv[0];
+                x.y += round_bf(y[1]) * gv[1];
+                x.z += round_bf(y[2]) * gv[2];
+                x.w += round_bf(y[3]) * gv[3];
+                *p = x;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// True when the shape fits this kernel (the caller falls back to the 128 x 128 kernel otherwise).
+bool ovd_gemm256_applicable(long lda, long ldw, int M, int N, int K) {
+    return N % TN == 0 && K % TK == 0 && K >= 3 * TK && M >= 2 * TM && (long)M * lda * 2 < (1L << 32) &&
+           (long)N * ldw * 2 < (1L << 32);
+}
+
+int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, const bf16_t* bias, void* out,
+                          long ldo, const float* gate, int M, int N, int K, int epilogue, hipStream_t st) {
+    OVD_REQUIRE(ovd_gemm256_applicable(lda, ldw, M, N, K), "gemm256: shape M=%d N=%d K=%d not supported", M, N, K);
+    const int tiles_m = ceil_div(M, TM), tiles_n = N / TN;
+    dim3 grid(tiles_m * tiles_n), blk(512);
+    const size_t lds = NSTAGE * STAGE;
+#define GEMM_CASE(E)                                                                                      \
+    case E: {                                                                                             \
+        static bool attr_set = false;                                                                     \
+        if (!attr_set) {                                                                                  \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<E>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+                OVD_FAIL("gemm256: cannot reserve %zu bytes of LDS", lds);                                 \
+            attr_set = true;                                                                              \
+        }                                                                                                 \
+        hipLaunchKernelGGL((gemm256_kernel<E>), grid, blk, lds, st, A, lda, W, ldw, bias, out, ldo, gate,  \
+                           M, N, K, tiles_m, tiles_n);                                                    \
+    } break;
+    switch (epilogue) {
+        GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID)
+    }
+#undef GEMM_CASE
+    OVD_CHECK_LAUNCH("gemm256_bf16");
+    return 0;
+}

@@ -107,7 +107,9 @@ def test_rmsnorm_rope_batched_and_offset(H):
     assert torch.equal(out2.cpu(), out[20:40].cpu())
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (130, 256, 192), (300, 384, 1536), (257, 1536, 8960)])
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (130, 256, 192), (300, 384, 1536), (257, 1536, 8960),
+                                   # M >= 512 with N % 256 == 0: the 256 x 256 ring-pipelined kernel
+                                   (777, 256, 128), (1100, 512, 1536), (513, 1536, 192), (1024, 768, 4480)])
 def test_gemm_epilogues(H, M, N, K):
     a = rb(syn.randn("g.a", (M, K), 3))
     w = rb(syn.uniform("g.w", (N, K), 1 / math.sqrt(K), 3))

@@ -52,7 +52,7 @@ def attn(B, Lq, Lk, N, k_len=None, check=False, strided_q=False, fused_kv=False,
     print(msg, flush=True)
 
 
-def gemm(M, N, K, epi=0):
+def gemm(M, N, K, epi=0, check=False):
     a = torch.randn(M, K, device="cuda").to(BF16)
     w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF16)
     b = torch.randn(N, device="cuda").to(BF16)
@@ -60,7 +60,17 @@ def gemm(M, N, K, epi=0):
     if epi >= 2:
         out.zero_()
     ms = timeit(lambda: H.gemm(a, w, out, b, epi))
-    print(f"gemm M{M} N{N} K{K} epi{epi}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+    msg = f"gemm M{M} N{N} K{K} epi{epi}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s"
+    if check:
+        if epi >= 2:
+            out.zero_()
+        H.gemm(a, w, out, b, epi)
+        ref = (a.float() @ w.float().t() + b.float())
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref.to(BF16).float(), approximate="tanh")
+        err = (out.float() - ref.to(BF16).float()).abs().max().item()
+        msg += f"  max|err| vs torch {err:.3e} (ref max {ref.abs().max().item():.2f})"
+    print(msg, flush=True)
 
 
 def vae(latent=(16, 13, 60, 104), encode=False):
@@ -103,6 +113,11 @@ if __name__ == "__main__":
         attn(2, 20280, 64, 12, strided_q=True)
         attn(2, 20280, 512, 12, strided_q=True, fused_kv=True)
         attn(2, 20280, 512, 12, strided_q=True, fused_kv=True, same_rows=20)
+    if "gemmcheck" in args.what:
+        gemm(1000, 512, 128, 0, check=True)
+        gemm(777, 256, 192, 3, check=True)
+        gemm(4096, 1536, 1536, 1, check=True)
+        gemm(40560, 1536, 1536, 2, check=True)
     if "gemm" in args.what:
         M = 40560
         gemm(M, 4608, 1536, 0)      # fused QKV
