@@ -80,6 +80,17 @@ int ovd_flash_attn_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t
                             int64_t v_ld, int64_t o_ld, int64_t q_bs, int64_t k_bs, int64_t v_bs,
                             int64_t o_bs, float softmax_scale, void* stream);
 
+/* As ovd_flash_attn_fwd_bf16, with key k_len - 1 counted last_key_copies (>= 1) times: its
+ * probability enters the row sum and P V with that weight.  For cross-attention over a context
+ * zero-padded to text_len (model.py:480-485 pads, model.py:174 attends every padded key): all
+ * padded rows of K and of V are identical, so rows [n, text_len) can be given as the single
+ * key n with last_key_copies = text_len - n and k_len = n + 1; the result equals attending
+ * every padded key up to fp32 summation order. */
+int ovd_flash_attn_tail_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, int B,
+                                 int Lq, int Lk, int N, int head_dim, int k_len, int last_key_copies,
+                                 int64_t q_ld, int64_t k_ld, int64_t v_ld, int64_t o_ld, int64_t q_bs,
+                                 int64_t k_bs, int64_t v_bs, int64_t o_bs, float softmax_scale, void* stream);
+
 /* [Cin,T,H,W] (fp32, or bf16 when lat_is_bf16) -> bf16 rows [f*h*w, Cin*pt*ph*pw] in
  * (f,h,w) token order and (cin,pt,ph,pw) column order, ready for ovd_gemm_bf16 against
  * the flattened Conv3d weight.  Replaces the im2col half of nn.Conv3d with

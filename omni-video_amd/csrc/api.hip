@@ -22,7 +22,7 @@ int ovd_impl_rmsnorm_rope(const bf16_t*, long, const bf16_t*, const float*, int,
 int ovd_impl_gemm_bf16(const bf16_t*, long, const bf16_t*, long, const bf16_t*, void*, long, const float*, int, int,
                        int, int, hipStream_t);
 int ovd_impl_attn_fwd(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, long, long,
-                      long, long, long, long, long, long, float, hipStream_t);
+                      long, long, long, long, long, long, float, int, hipStream_t);
 int ovd_impl_patchify(const void*, int, bf16_t*, int, int, int, int, int, int, int, hipStream_t);
 int ovd_impl_time_sinusoid(const double*, const int*, int, float*, int, hipStream_t);
 int ovd_impl_gemv_f32(const float*, const bf16_t*, const bf16_t*, float*, int, int, int, hipStream_t);
@@ -88,7 +88,16 @@ int ovd_flash_attn_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t
                             float softmax_scale, void* stream) {
     NONNULL(q); NONNULL(k); NONNULL(v); NONNULL(out);
     return ovd_impl_attn_fwd(q, k, v, out, B, Lq, Lk, N, head_dim, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs,
-                             o_bs, softmax_scale, ST(stream));
+                             o_bs, softmax_scale, 1, ST(stream));
+}
+
+int ovd_flash_attn_tail_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, int B,
+                                 int Lq, int Lk, int N, int head_dim, int k_len, int last_key_copies, int64_t q_ld,
+                                 int64_t k_ld, int64_t v_ld, int64_t o_ld, int64_t q_bs, int64_t k_bs,
+                                 int64_t v_bs, int64_t o_bs, float softmax_scale, void* stream) {
+    NONNULL(q); NONNULL(k); NONNULL(v); NONNULL(out);
+    return ovd_impl_attn_fwd(q, k, v, out, B, Lq, Lk, N, head_dim, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs,
+                             o_bs, softmax_scale, last_key_copies, ST(stream));
 }
 
 int ovd_patchify(const void* lat, int lat_is_bf16, uint16_t* rows, int Cin, int T, int H, int W, int pt, int ph,

@@ -72,12 +72,17 @@ __device__ __forceinline__ float lane_max32(const f32x16& a, const f32x16& b) {
     return __builtin_fmaxf(mx, b[15]);
 }
 
+// Last-tile fix-ups: keys at or beyond k_len are masked; key k_len - 1 gets tail_bias added
+// to its raw score (= log2(c) / scale_log2 when that key stands for c identical keys, so that
+// its probability, its share of the row sum and of P V all count c times; 0 otherwise).
 template <bool MASK>
-__device__ __forceinline__ void mask_scores(f32x16& s0, f32x16& s1, int key0, int k_len, int hi) {
+__device__ __forceinline__ void mask_scores(f32x16& s0, f32x16& s1, int key0, int k_len, float tail_bias, int hi) {
     if (MASK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key == k_len - 1) s0[r] += tail_bias;
+            if (key + 32 == k_len - 1) s1[r] += tail_bias;
             if (key >= k_len) s0[r] = -1e30f;
             if (key + 32 >= k_len) s1[r] = -1e30f;
         }
@@ -115,7 +120,7 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
                                           const f32x16& c0, const f32x16& c1, f32x16& n0, f32x16& n1,
                                           float& mx, bool& need, const char* sk_next, const char* sv_cur,
                                           Stream& ks_, char* k_dst, Stream& vs_, char* v_dst, int key0_next,
-                                          int k_len, float scale_log2, int lane) {
+                                          int k_len, float tail_bias, float scale_log2, int lane) {
     const int l31 = lane & 31, hi = lane >> 5;
     if (need) {
         const float m_new = __builtin_fmaxf(m_c, mx);
@@ -187,7 +192,7 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
         if (ks == 7) READ_V(0, vf[0]);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (HAS_NEXT) mask_scores<MASK_NEXT>(n0, n1, key0_next, k_len, hi);
+    if (HAS_NEXT) mask_scores<MASK_NEXT>(n0, n1, key0_next, k_len, tail_bias, hi);
 
     // ---- O^T += V^T P^T of the current tile; beside it the last 8 scores' softmax, then the
     // next tile's lane maximum
@@ -224,7 +229,7 @@ template <int NW>
 __device__ __forceinline__ void
 attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
               bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,
-              long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2) {
+              long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2] | V[2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -250,7 +255,7 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
         for (int j = 0; j < 16; ++j) o_acc[i][j] = 0.f;
     float m_c = -1e30f, l_run = 0.f;
     const int nt = (k_len + BKV - 1) / BKV;
-    const bool partial = nt * BKV > k_len;
+    const bool partial = nt * BKV > k_len || tail_bias != 0.f;     // last tile needs the fix-up pass
 
     // staging pass i of wave w covers tile rows 4*(i*NW + w) .. +3 (one wave instruction = 4 rows,
     // lane-linear in LDS); the XOR swizzle of k_off / v_off is applied to the SOURCE chunk
@@ -290,7 +295,7 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
             a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], a1, 0, 0, 0);
         }
-        if (nt == 1 && partial) mask_scores<true>(a0, a1, 0, k_len, hi);
+        if (nt == 1 && partial) mask_scores<true>(a0, a1, 0, k_len, tail_bias, hi);
         mx = half_max(lane_max32(a0, a1)) * scale_log2;
         need = __any(mx > m_c + RESCALE_THR);
     }
@@ -306,7 +311,7 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
                                            smem + (2 + (t_ & 1)) * KV_TILE_BYTES, kst,                   \
                                            wave_lds + (t_ & 1) * KV_TILE_BYTES, vst,                     \
                                            wave_lds + (2 + ((t_ + 1) & 1)) * KV_TILE_BYTES,              \
-                                           (t_ + 1) * BKV, k_len, scale_log2, lane);                     \
+                                           (t_ + 1) * BKV, k_len, tail_bias, scale_log2, lane);          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
         __syncthreads();                                                                                 \
     } while (0)
@@ -354,9 +359,9 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
     __global__ void __launch_bounds__(64 * NW, 2) attn_pipe_kernel_w##NW(                                \
         const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,       \
         bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,   \
-        long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2) {                                  \
+        long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias) {                 \
         attn_fwd_pipe<NW>(Q, K, V, O, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs,     \
-                          scale_log2);                                                                   \
+                          scale_log2, tail_bias);                                                        \
     }
 ATTN_KERNEL(4)
 ATTN_KERNEL(8)
@@ -366,10 +371,11 @@ ATTN_KERNEL(8)
 
 // q [B,Lq,N,128], k/v [B,Lk,N,128], out [B,Lq,N,128]; *_ld = elements between
 // consecutive tokens, *_bs = elements between batch entries (so the fused QKV
-// projection buffer can be addressed in place).  Keys at index >= k_len are masked.
+// projection buffer can be addressed in place).  Keys at index >= k_len are masked; key
+// k_len - 1 counts last_key_copies times (a run of identical trailing keys folded into one).
 int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Lq, int Lk,
                       int N, int D, int k_len, long q_ld, long k_ld, long v_ld, long o_ld, long q_bs, long k_bs,
-                      long v_bs, long o_bs, float softmax_scale, hipStream_t st) {
+                      long v_bs, long o_bs, float softmax_scale, int last_key_copies, hipStream_t st) {
     OVD_REQUIRE(D == HD, "attention: head_dim %d not supported (only 128)", D);
     OVD_REQUIRE(B > 0 && N > 0 && Lq > 0 && Lk > 0, "attention: empty problem B=%d N=%d Lq=%d Lk=%d", B, N, Lq, Lk);
     OVD_REQUIRE(k_len > 0 && k_len <= Lk, "attention: k_len=%d outside (0, Lk=%d]", k_len, Lk);
@@ -378,10 +384,12 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
     OVD_REQUIRE(q_ld >= (long)N * D && k_ld >= (long)N * D && v_ld >= (long)N * D && o_ld >= (long)N * D,
                 "attention: token stride shorter than N*D");
     OVD_REQUIRE(softmax_scale > 0.f, "attention: softmax_scale must be positive");
+    OVD_REQUIRE(last_key_copies >= 1, "attention: last_key_copies=%d must be at least 1", last_key_copies);
     OVD_REQUIRE(((long)Lk + 4 * BKV) * (k_ld > v_ld ? k_ld : v_ld) * 2 < (1L << 32),
                 "attention: one (batch, head) slab of K/V must span less than 4 GiB (Lk=%d)", Lk);
     const size_t lds = 4 * KV_TILE_BYTES;
     const float scale_log2 = softmax_scale * 1.4426950408889634f;
+    const float tail_bias = last_key_copies > 1 ? log2f((float)last_key_copies) / scale_log2 : 0.f;
     // 8-wave workgroups (256 query rows) unless that grid would leave compute units idle;
     // OVD_ATTN_WAVES=4|8 overrides (tuning aid)
     static int forced = -1;
@@ -402,7 +410,7 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
         }                                                                                                  \
         dim3 grid(ceil_div(Lq, 32 * NW), N, B), blk(64 * NW);                                              \
         hipLaunchKernelGGL(KERNEL, grid, blk, lds, st, q, k, v, out, Lq, Lk, k_len, q_ld, k_ld, v_ld,      \
-                           o_ld, q_bs, k_bs, v_bs, o_bs, scale_log2);                                      \
+                           o_ld, q_bs, k_bs, v_bs, o_bs, scale_log2, tail_bias);                           \
     }
     if (waves == 8) ATTN_CASE(attn_pipe_kernel_w8, 8) else ATTN_CASE(attn_pipe_kernel_w4, 4)
 #undef ATTN_CASE

@@ -96,7 +96,38 @@ __device__ __forceinline__ void k_tile(f32x4 (&acc)[4][8], const char* smem, int
     __builtin_amdgcn_s_barrier();
 }
 
-template <int EPI>
+// One K-tile as a single phase of 32 MFMAs (variant used when PHASES == 1): 12 fragment reads,
+// both parts of K-tile kt + 2 put in flight, one counted wait, two barriers.
+template <bool STAGE_NEXT, int VMCNT>
+__device__ __forceinline__ void k_tile1(f32x4 (&acc)[4][8], const char* smem, int kt, const Src& sa, const Src& sw,
+                                        int lane_off, int a_rd, int w_rd, int wave) {
+    const char* st = smem + (kt & (NSTAGE - 1)) * STAGE;
+    char* nx = const_cast<char*>(smem) + ((kt + 2) & (NSTAGE - 1)) * STAGE + wave * 1024;
+    const long kb = (long)(kt + 2) * TK * 2;
+    bf16x8 wf[4], af[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[t] = lds_frag(st + PART + w_rd + t * 1024 + lane_off);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) af[t] = lds_frag(st + a_rd + t * 1024 + lane_off);
+    if (STAGE_NEXT) {
+        stage_part(sw, kb, nx + PART);
+        stage_part(sa, kb, nx);
+    }
+    if (VMCNT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (VMCNT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int EPI, int PHASES>
 __global__ void __launch_bounds__(512, 2)
 gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
                const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
@@ -149,21 +180,36 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
 
     const int nk = K / TK;      // >= 3 (checked on the host)
     char* const wdst = smem + wave * 1024;
+    if (PHASES == 2) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        stage_part(sw, (long)t * TK * 2, wdst + t * STAGE + PART);
-        stage_part(sa, (long)t * TK * 2, wdst + t * STAGE);
+        for (int t = 0; t < 3; ++t) {
+            stage_part(sw, (long)t * TK * 2, wdst + t * STAGE + PART);
+            stage_part(sa, (long)t * TK * 2, wdst + t * STAGE);
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // K-tile 0 landed (this wave's share)
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: half a phase behind
+        int kt = 0;
+        for (; kt < nk - 3; ++kt) k_tile<true, 8>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
+        k_tile<false, 4>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
+        k_tile<false, 0>(acc, smem, kt + 1, sa, sw, lane_off, a_rd, w_rd, wave);
+        k_tile<false, -1>(acc, smem, kt + 2, sa, sw, lane_off, a_rd, w_rd, wave);
+        if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            stage_part(sw, (long)t * TK * 2, wdst + t * STAGE + PART);
+            stage_part(sa, (long)t * TK * 2, wdst + t * STAGE);
+        }
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        int kt = 0;
+        for (; kt < nk - 2; ++kt) k_tile1<true, 4>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
+        k_tile1<false, 0>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
+        k_tile1<false, -1>(acc, smem, kt + 1, sa, sw, lane_off, a_rd, w_rd, wave);
+        if (wr == 0) __builtin_amdgcn_s_barrier();
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // K-tile 0 landed (this wave's share)
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: half a phase behind
-
-    int kt = 0;
-    for (; kt < nk - 3; ++kt) k_tile<true, 8>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
-    k_tile<false, 4>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
-    k_tile<false, 0>(acc, smem, kt + 1, sa, sw, lane_off, a_rd, w_rd, wave);
-    k_tile<false, -1>(acc, smem, kt + 2, sa, sw, lane_off, a_rd, w_rd, wave);
-    if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
 
     // epilogue: lane holds out[m][n..n+3], m = row0 + wr*128 + mt*16 + fr, n = col0 + wc*64 + nt*16 + fq*4
     const int fr = lane & 15, fq = lane >> 4;
@@ -233,16 +279,27 @@ int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, 
     case E: {                                                                                             \
         static bool attr_set = false;                                                                     \
         if (!attr_set) {                                                                                  \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<E>),                    \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<E, PH>),                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
                 OVD_FAIL("gemm256: cannot reserve %zu bytes of LDS", lds);                                 \
             attr_set = true;                                                                              \
         }                                                                                                 \
-        hipLaunchKernelGGL((gemm256_kernel<E>), grid, blk, lds, st, A, lda, W, ldw, bias, out, ldo, gate,  \
+        hipLaunchKernelGGL((gemm256_kernel<E, PH>), grid, blk, lds, st, A, lda, W, ldw, bias, out, ldo, gate, \
                            M, N, K, tiles_m, tiles_n);                                                    \
     } break;
-    switch (epilogue) {
-        GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID)
+    static int phases = -1;
+    if (phases < 0) {
+        const char* e = getenv("OVD_GEMM_PHASES");
+        phases = (e && atoi(e) == 2) ? 2 : 1;
+    }
+    if (phases == 2) {
+#define PH 2
+        switch (epilogue) { GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) }
+#undef PH
+    } else {
+#define PH 1
+        switch (epilogue) { GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) }
+#undef PH
     }
 #undef GEMM_CASE
     OVD_CHECK_LAUNCH("gemm256_bf16");

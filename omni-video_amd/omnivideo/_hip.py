@@ -20,6 +20,7 @@ SIGNATURES = {
     "ovd_rmsnorm_rope_bf16": [_p, _l, _p, _p, _i, _p, _l, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p],
     "ovd_gemm_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _p],
     "ovd_flash_attn_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p],
+    "ovd_flash_attn_tail_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p],
     "ovd_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_time_sinusoid": [_p, _p, _i, _p, _i, _p],
     "ovd_gemv_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -152,9 +153,11 @@ def gemm(a, w, out, bias=None, epilogue=EPI_BF16, gate=None):
     return out
 
 
-def flash_attn(q, k, v, out, k_len=None, softmax_scale=None):
+def flash_attn(q, k, v, out, k_len=None, softmax_scale=None, last_key_copies=1):
     """q [B,Lq,N,D], k/v [B,Lk,N,D], out [B,Lq,N,D] bf16; the (N,D) dims must be dense, the
-    token and batch dims may be strided (views into a fused projection buffer)."""
+    token and batch dims may be strided (views into a fused projection buffer).  Keys at or
+    beyond k_len are masked; key k_len - 1 counts last_key_copies times (a run of identical
+    trailing keys folded into one)."""
     B, Lq, N, D = q.shape
     Lk = k.shape[1]
     for t in (q, k, v, out):
@@ -163,8 +166,14 @@ def flash_attn(q, k, v, out, k_len=None, softmax_scale=None):
     if k.shape != v.shape or k.shape[0] != B or k.shape[2:] != q.shape[2:] or out.shape != q.shape:
         raise ValueError("attention: shape mismatch")
     scale = float(softmax_scale) if softmax_scale is not None else D ** -0.5
+    kl = int(Lk if k_len is None else k_len)
+    if int(last_key_copies) != 1:
+        _call("ovd_flash_attn_tail_fwd_bf16", _ptr(q, BF16), _ptr(k, BF16), _ptr(v, BF16), _ptr(out, BF16), B, Lq, Lk,
+              N, D, kl, int(last_key_copies), q.stride(1), k.stride(1), v.stride(1), out.stride(1), q.stride(0),
+              k.stride(0), v.stride(0), out.stride(0), scale, _stream())
+        return out
     _call("ovd_flash_attn_fwd_bf16", _ptr(q, BF16), _ptr(k, BF16), _ptr(v, BF16), _ptr(out, BF16), B, Lq, Lk, N, D,
-          int(Lk if k_len is None else k_len), q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+          kl, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
           q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream())
     return out
 

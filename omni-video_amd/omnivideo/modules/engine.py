@@ -61,9 +61,16 @@ def build_rope_table(head_dim, rows, device, theta=10000.0):
 class ContextCache:
     """Embedded context and per-layer cross-attention K/V for `nb` guidance branches."""
 
-    def __init__(self, kv, text_len):
+    def __init__(self, kv, text_len, n_real=None):
         self.kv = kv            # [layers, nb, text_len, 2C] bf16: K (normalised) | V
         self.text_len = text_len
+        # Rows [n_real, text_len) of every branch come from zero padding (model.py:480-485): the
+        # same input row through the same per-row kernels, so their K and V rows are bit-identical.
+        # The reference attends all of them (model.py:174, no k_lens); cross-attention reads keys
+        # [0, n_real] and counts key n_real text_len - n_real times.
+        n_real = text_len if n_real is None else min(int(n_real), text_len)
+        self.k_len = min(n_real + 1, text_len)
+        self.last_key_copies = text_len - self.k_len + 1
 
 
 class TorchGroupComm:
@@ -199,7 +206,7 @@ class DiTEngine:
             H.gemm(emb, L["w_ckv"], flat, L["b_ckv"], H.EPI_BF16)
             kview = flat[:, :C]
             H.rmsnorm_rope(kview, L["cnk"], kview, self.head_dim, self.eps)
-        return ContextCache(kv, text_len)
+        return ContextCache(kv, text_len, max(int(c.reshape(-1, self.text_dim).shape[0]) for c in contexts))
 
     # ------------------------------------------------------------------ attention variants
     def _self_attention(self, q4, k4, v4, att4):
@@ -281,7 +288,8 @@ class DiTEngine:
             H.gemm(self.h, L["w_cq"], qc, L["b_cq"], H.EPI_BF16)
             H.rmsnorm_rope(qc, L["cnq"], qc, D, self.eps)
             kvl = ctx.kv[l]
-            H.flash_attn(q4, kvl[:, :, :C].unflatten(2, (N, D)), kvl[:, :, C:].unflatten(2, (N, D)), att4)
+            H.flash_attn(q4, kvl[:, :, :C].unflatten(2, (N, D)), kvl[:, :, C:].unflatten(2, (N, D)), att4,
+                         k_len=ctx.k_len, last_key_copies=ctx.last_key_copies)
             H.gemm(att2, L["w_co"], x2, L["b_co"], H.EPI_RESID)
             # feed-forward (model.py:251-254)
             H.layernorm_modulate(x2, self.h, self.eps, shift=mod[3], scale=mod[4])

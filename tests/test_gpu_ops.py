@@ -193,6 +193,26 @@ def test_flash_attention_softmax_spike(H):
     assert_bf16_close(out[0], ref, ulps=2.0, atol=6e-3)
 
 
+@pytest.mark.parametrize("Lq,Lk,n_real", [(130, 512, 37), (70, 200, 63), (257, 6144, 127), (40, 96, 95), (33, 64, 0)])
+def test_flash_attention_folded_padding(H, Lq, Lk, n_real):
+    """Keys [n_real, Lk) are one repeated row (a zero-padded context after the embedding): reading
+    keys [0, n_real] with the last one counted Lk - n_real times must equal attending all Lk keys
+    (reference semantics, model.py:174), here checked against the oracle on the full key set."""
+    N, D = 2, 128
+    q = rb(syn.randn("fp.q", (1, Lq, N, D), 8))
+    k = rb(syn.randn("fp.k", (1, Lk, N, D), 8))
+    v = rb(syn.randn("fp.v", (1, Lk, N, D), 8))
+    k[:, n_real:] = k[:, n_real:n_real + 1]
+    v[:, n_real:] = v[:, n_real:n_real + 1]
+    out = torch.empty(1, Lq, N, D, device="cuda", dtype=BF16)
+    H.flash_attn(dev(q, BF16), dev(k, BF16), dev(v, BF16), out, k_len=n_real + 1, last_key_copies=Lk - n_real)
+    ref = O.attention(q[0], k[0], v[0], flow="fp32")
+    assert_bf16_close(out[0], ref, ulps=2.0, atol=6e-3)
+    full = torch.empty_like(out)
+    H.flash_attn(dev(q, BF16), dev(k, BF16), dev(v, BF16), full)
+    assert_bf16_close(out[0], full[0].float().cpu(), ulps=2.0, atol=6e-3)
+
+
 def test_flash_attention_strided_qkv(H):
     """q/k/v as views into one fused [B,L,3C] projection buffer."""
     B, L, N, D = 2, 130, 2, 128
