@@ -146,6 +146,20 @@ int ovd_cfg_unipc_step(const float* cond, const float* uncond, void* sample, voi
                        int64_t n, int sample_is_bf16, void* stream);
 #define OVD_UNIPC_COEF_STRIDE 16
 
+/* One DPM-Solver++ step (order <= 2, midpoint, flow prediction) on n latent elements:
+ *   v = uncond + guide * (cond - uncond)                       (x2x_gen_unified.py:484)
+ *   x0 = sample - sigma * v                                    (fm_solvers.py:383-385)
+ *   next = ratio*sample - b*x0 [ - half_b * inv_r0*(x0 - m1) ] (fm_solvers.py:455-466, :527-560)
+ *   m1 = x0                                                    (fm_solvers.py:748-751)
+ * sample is bf16 (sample_is_bf16, only ever the initial noise) or fp32; next is fp32 (the
+ * reference's prev_sample takes the dtype of the converted model output, fm_solvers.py:793)
+ * and may alias an fp32 sample.  coef is the host-built table [steps][8]: sigma, order, ratio,
+ * b, half_b, inv_r0; the row index is *step_ptr when step_ptr is non-NULL, else `step`. */
+int ovd_cfg_dpm_step(const float* cond, const float* uncond, const void* sample, float* next, float* m1,
+                     const float* coef, float guide_scale, const int* step_ptr, int step, int64_t n,
+                     int sample_is_bf16, void* stream);
+#define OVD_DPM_COEF_STRIDE 8
+
 /* *step_ptr += 1 on the device (advances the step counter inside a captured graph). */
 int ovd_step_advance(int* step_ptr, void* stream);
 

@@ -32,6 +32,8 @@ int ovd_impl_head_unpatchify(const float*, long, const bf16_t*, const bf16_t*, f
                              int, int, int, int, hipStream_t);
 int ovd_impl_cfg_unipc_step(const float*, const float*, void*, void*, float*, float*, const float*, float,
                             const int*, int, long, int, hipStream_t);
+int ovd_impl_cfg_dpm_step(const float*, const float*, const void*, float*, float*, const float*, float, const int*,
+                          int, long, int, hipStream_t);
 int ovd_impl_step_advance(int*, hipStream_t);
 int ovd_impl_conv3d_cl(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                        int, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int,
@@ -145,6 +147,15 @@ int ovd_cfg_unipc_step(const float* cond, const float* uncond, void* sample, voi
     OVD_REQUIRE(step_ptr != nullptr || step >= 0, "cfg_unipc: negative step");
     return ovd_impl_cfg_unipc_step(cond, uncond, sample, last_sample, m1, m2, coef, guide_scale, step_ptr, step, n,
                                    sample_is_bf16, ST(stream));
+}
+
+int ovd_cfg_dpm_step(const float* cond, const float* uncond, const void* sample, float* next, float* m1,
+                     const float* coef, float guide_scale, const int* step_ptr, int step, int64_t n,
+                     int sample_is_bf16, void* stream) {
+    NONNULL(cond); NONNULL(uncond); NONNULL(sample); NONNULL(next); NONNULL(m1); NONNULL(coef);
+    OVD_REQUIRE(step_ptr != nullptr || step >= 0, "cfg_dpm: negative step");
+    return ovd_impl_cfg_dpm_step(cond, uncond, sample, next, m1, coef, guide_scale, step_ptr, step, n,
+                                 sample_is_bf16, ST(stream));
 }
 
 int ovd_step_advance(int* step_ptr, void* stream) {

@@ -87,7 +87,57 @@ __global__ void __launch_bounds__(256) cfg_unipc_kernel(const float* __restrict_
     }
 }
 
+// Classifier-free-guidance combine + one DPM-Solver++ (order <= 2, midpoint) step
+// (omnivideo/utils/fm_solvers.py:383-385 convert_model_output, :455-466 first order,
+// :527-560 second order, :748-751 history).  Row layout of its coefficient table:
+enum { DP_SIGMA = 0, DP_ORDER, DP_RATIO, DP_B, DP_HALF_B, DP_INV_R0, DP_COUNT = 8 };
+
+template <typename T>
+__global__ void __launch_bounds__(256) cfg_dpm_kernel(const float* __restrict__ cond, const float* __restrict__ uncond,
+                                                      const T* __restrict__ sample, float* __restrict__ next,
+                                                      float* __restrict__ m1, const float* __restrict__ coef,
+                                                      float guide, const int* __restrict__ step_ptr, int step,
+                                                      long n) {
+    const int s = step_ptr ? *step_ptr : step;
+    const float* cf = coef + (long)s * DP_COUNT;
+    const float sigma = cf[DP_SIGMA], ratio = cf[DP_RATIO], b = cf[DP_B], half_b = cf[DP_HALF_B];
+    const float inv_r0 = cf[DP_INV_R0];
+    const bool second = cf[DP_ORDER] == 2.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float c = cond[i], u = uncond[i];
+        const float v = u + guide * (c - u);
+        const float xs = ldv<T>(sample, i);
+        const float x0 = xs - sigma * v;
+        const float t1 = ratio * xs;
+        float x = t1 - b * x0;
+        if (second) {
+            const float d1 = inv_r0 * (x0 - m1[i]);
+            x = x - half_b * d1;
+        }
+        m1[i] = x0;
+        next[i] = x;
+    }
+}
+
 }  // namespace
+
+int ovd_impl_cfg_dpm_step(const float* cond, const float* uncond, const void* sample, float* next, float* m1,
+                          const float* coef, float guide, const int* step_ptr, int step, long n, int sample_is_bf16,
+                          hipStream_t st) {
+    OVD_REQUIRE(n >= 0, "cfg_dpm: negative size");
+    OVD_REQUIRE(!sample_is_bf16 || (const void*)next != sample, "cfg_dpm: a bf16 sample cannot be updated in place");
+    if (n == 0) return 0;
+    int blocks = ceil_div(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (sample_is_bf16)
+        hipLaunchKernelGGL(cfg_dpm_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, cond, uncond, (const bf16_t*)sample,
+                           next, m1, coef, guide, step_ptr, step, n);
+    else
+        hipLaunchKernelGGL(cfg_dpm_kernel<float>, dim3(blocks), dim3(256), 0, st, cond, uncond, (const float*)sample,
+                           next, m1, coef, guide, step_ptr, step, n);
+    OVD_CHECK_LAUNCH("cfg_dpm_step");
+    return 0;
+}
 
 int ovd_impl_cfg_unipc_step(const float* cond, const float* uncond, void* sample, void* last_sample, float* m1,
                             float* m2, const float* coef, float guide, const int* step_ptr, int step, long n,

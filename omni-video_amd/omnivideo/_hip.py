@@ -28,6 +28,7 @@ SIGNATURES = {
     "ovd_head_modulation": [_p, _p, _p, _i, _p],
     "ovd_head_unpatchify": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_cfg_unipc_step": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
+    "ovd_cfg_dpm_step": [_p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
     "ovd_step_advance": [_p, _p],
     "ovd_vae_conv3d_f32": [_p] * 7 + [_i] + [_p] * 4 + [_i] * 14 + [_p],
     "ovd_vae_voxel_rnorm": [_p, _p, _l, _i, _p],
@@ -38,6 +39,7 @@ SIGNATURES = {
 
 EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_RESID = 0, 1, 2, 3
 UNIPC_COEF_STRIDE = 16
+DPM_COEF_STRIDE = 8
 
 
 def lib():
@@ -240,6 +242,20 @@ def cfg_unipc_step(cond, uncond, sample, last_sample, m1, m2, coef, guide_scale,
         raise TypeError("cfg_unipc: sample/last_sample must share a bf16 or fp32 dtype")
     _call("ovd_cfg_unipc_step", _ptr(cond, F32), _ptr(uncond, F32), _ptr(sample), _ptr(last_sample), _ptr(m1, F32),
           _ptr(m2, F32), _ptr(coef, F32), float(guide_scale), _ptr(step_ptr, torch.int32, True), int(step), n,
+          int(sample.dtype == BF16), _stream())
+
+
+def cfg_dpm_step(cond, uncond, sample, nxt, m1, coef, guide_scale, step=0, step_ptr=None):
+    """Fused guidance + DPM-Solver++ step: reads `sample` (bf16 or fp32), writes the fp32 `nxt`
+    (which may be `sample` itself when that is fp32) and the x0 history `m1`."""
+    n = sample.numel()
+    for t in (cond, uncond, m1, nxt, sample):
+        if t.numel() != n or not t.is_contiguous():
+            raise ValueError("cfg_dpm: buffers must be contiguous and equally sized")
+    if sample.dtype not in (BF16, F32):
+        raise TypeError("cfg_dpm: sample must be bf16 or fp32")
+    _call("ovd_cfg_dpm_step", _ptr(cond, F32), _ptr(uncond, F32), _ptr(sample), _ptr(nxt, F32), _ptr(m1, F32),
+          _ptr(coef, F32), float(guide_scale), _ptr(step_ptr, torch.int32, True), int(step), n,
           int(sample.dtype == BF16), _stream())
 
 

@@ -27,6 +27,7 @@ import torch.distributed as dist
 
 from . import _hip as H
 from .modules.unified_model import UnifiedWanWithMixedConditionModel
+from .utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
 from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -193,9 +194,8 @@ class OmniVideoX2XUnified:
         initial latents instead of drawing them on the device), `return_latents`."""
         if precision_dtype != torch.bfloat16:
             raise NotImplementedError("the HIP path computes in bf16 (the reference's GPU setting)")
-        if sample_solver != "unipc":
-            raise NotImplementedError("Unsupported solver." if sample_solver != "dpm++"
-                                      else "dpm++ is not built yet; use unipc (the default)")
+        if sample_solver not in ("unipc", "dpm++"):
+            raise NotImplementedError("Unsupported solver.")
         if condition_mode not in ("auto", "full"):
             raise NotImplementedError("only condition_mode 'auto'/'full' reaches the DiT in the reference")
         F_ = frame_num
@@ -246,9 +246,17 @@ class OmniVideoX2XUnified:
 
         with torch.no_grad():
             boundary = self.boundary * self.num_train_timesteps
-            sched = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
-                                                use_dynamic_shifting=False)
-            sched.set_timesteps(sampling_steps, device="cpu", shift=shift)
+            if sample_solver == "unipc":        # reference :409-416
+                sched = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                                    use_dynamic_shifting=False)
+                sched.set_timesteps(sampling_steps, device="cpu", shift=shift)
+            else:                               # reference :417-426
+                sched = FlowDPMSolverMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                                        use_dynamic_shifting=False)
+                retrieve_timesteps(sched, device="cpu", sigmas=get_sampling_sigmas(sampling_steps, shift))
+                # DPM-Solver++ samples are float32 after the first step (fm_solvers.py:793); the
+                # bf16 noise converts exactly, and the DiT rounds its input to bf16 either way
+                lat = lat.float()
             # null AR vision: two rows of 1e-6 (reference :433-449)
             ar_null = None
             if ar_vision_input is not None:

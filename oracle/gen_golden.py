@@ -4,7 +4,7 @@ modules (loaded by oracle/ref_loader.py from /root/reference) on CPU in float32.
 Only outputs are stored: weights and inputs are regenerated from their names by
 omnivideo.utils.synthetic, so the fixtures stay small.  Run from the repo root:
 
-    python oracle/gen_golden.py [dit] [unipc] [vae]
+    python oracle/gen_golden.py [dit] [unipc] [dpm] [vae]
 
 The reference tree exists only in the build container; the committed .npz files are
 what travels.
@@ -130,14 +130,42 @@ def gen_unipc():
     print("unipc.npz:", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def gen_dpm():
+    ns = ref_loader.load()
+    out = {}
+    for steps, shift in ((20, 5.0), (40, 5.0), (50, 5.0), (50, 12.0)):
+        s = ns.dpm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        ts, _ = ns.dpm.retrieve_timesteps(s, device="cpu", sigmas=ns.dpm.get_sampling_sigmas(steps, shift))
+        out[f"timesteps_{steps}_{shift:g}"] = ts.numpy()
+        out[f"sigmas_{steps}_{shift:g}"] = s.sigmas.numpy()
+    for dt_name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        for steps in (20, 3, 1):
+            s = ns.dpm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+            ts, _ = ns.dpm.retrieve_timesteps(s, device="cpu", sigmas=ns.dpm.get_sampling_sigmas(steps, 5.0))
+            lat = syn.randn("dpm.noise", (16, 2, 4, 6), 7).to(dt)
+            traj = []
+            for t in ts:
+                c = linear_model(lat, t, "c")
+                u = linear_model(lat, t, "u")
+                v = u + 3.0 * (c - u)
+                lat = s.step(v.unsqueeze(0), t, lat.unsqueeze(0), return_dict=False)[0].squeeze(0)
+                assert lat.dtype == torch.float32
+                traj.append(lat.float().clone())
+            out[f"traj_{dt_name}_{steps}"] = torch.stack(traj).numpy()
+    np.savez_compressed(os.path.join(GOLD, "dpm.npz"), **out)
+    print("dpm.npz:", {k: tuple(v.shape) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dit", "unipc", "vae"]
+    which = sys.argv[1:] or ["dit", "unipc", "dpm", "vae"]
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     if "dit" in which:
         gen_dit()
     if "unipc" in which:
         gen_unipc()
+    if "dpm" in which:
+        gen_dpm()
     if "vae" in which:
         from oracle import gen_golden_vae
         gen_golden_vae.main()

@@ -105,6 +105,8 @@ def _install_stubs():
         SchedulerMixin=_SchedulerMixin, SchedulerOutput=_SchedulerOutput)
     mod("diffusers.utils", deprecate=lambda *a, **k: None,
         is_scipy_available=lambda: False)
+    mod("diffusers.utils.torch_utils", randn_tensor=lambda shape, generator=None, device=None, dtype=None:
+        torch.randn(shape, generator=generator, device=device, dtype=dtype))
 
 
 def exact_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_scale=None,
@@ -140,7 +142,7 @@ def _load(subdir, fname, modname):
 @functools.lru_cache(maxsize=None)
 def load():
     """Returns a namespace with the reference's hot-path modules:
-    .model .attention .unified_model .visual_context_adapter .vae2_1 .unipc"""
+    .model .attention .unified_model .visual_context_adapter .vae2_1 .unipc .dpm"""
     if not available():
         raise RuntimeError(f"reference tree not found at {REF_ROOT}")
     _install_stubs()
@@ -159,4 +161,5 @@ def load():
     ns.unified_model = _load("modules", "unified_model.py", "unified_model")
     ns.vae2_1 = _load("modules", "vae2_1.py", "vae2_1")
     ns.unipc = _load("utils", "fm_solvers_unipc.py", "fm_solvers_unipc")
+    ns.dpm = _load("utils", "fm_solvers.py", "fm_solvers")
     return ns

@@ -5,6 +5,7 @@ import torch
 
 from omnivideo.utils import synthetic as syn
 from oracle import dit as O
+from oracle import dpm as D
 from oracle import unipc as U
 
 pytestmark = pytest.mark.gpu
@@ -53,6 +54,42 @@ def test_scheduler_step_interface_matches_oracle():
         torch.testing.assert_close(xg.cpu(), xo, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("steps", [20, 3, 1])
+def test_dpm_fused_step_kernel_matches_oracle(dt, steps):
+    """Guidance + DPM-Solver++ step in one launch: same float32 operations in the same order as
+    the reference's tensor expressions, so the trajectory is bit-identical to the oracle's."""
+    from omnivideo.utils.fm_solvers import (FlowDPMSolverMultistepScheduler, get_sampling_sigmas,
+                                            retrieve_timesteps)
+    s = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    ts, n = retrieve_timesteps(s, device="cuda", sigmas=get_sampling_sigmas(steps, 5.0))
+    orc = D.DPMpp(steps, 5.0)
+    assert n == steps and torch.equal(ts.cpu(), orc.timesteps) and torch.equal(s.sigmas, orc.sigmas)
+    xo = syn.randn("dpm.noise", (16, 2, 4, 6), 7).to(dt)
+    xg = torch.empty(xo.shape, dtype=F32, device="cuda")
+    for i, t in enumerate(orc.timesteps):
+        c, u = linear_model(xo, t, "c"), linear_model(xo, t, "u")
+        s.step_cfg(c.cuda(), u.cuda(), 3.0, xo.cuda(), out=xg)
+        xo = orc.step(u + 3.0 * (c - u), xo)
+        assert xo.dtype == F32 and torch.equal(xg.cpu(), xo), i
+
+
+def test_dpm_scheduler_step_interface_matches_oracle():
+    from omnivideo.utils.fm_solvers import FlowDPMSolverMultistepScheduler
+    s = FlowDPMSolverMultistepScheduler()
+    s.set_timesteps(5, device="cuda", shift=5.0)
+    x = syn.randn("dpm.noise", (1, 16, 2, 4, 6), 7).to(BF16)
+    with pytest.raises(TypeError, match="fp32"):
+        s.step_cfg(x.float().cuda(), x.float().cuda(), 1.0, x.cuda())
+    xg = s.step(x.float().cuda(), s.timesteps[0], x.cuda(), return_dict=False)[0]
+    assert xg.dtype == F32
+    sig = s.sigmas
+    x0 = x - sig[0] * x.float()
+    h = (torch.log(1 - sig[1]) - torch.log(sig[1])) - (torch.log(1 - sig[0]) - torch.log(sig[0]))
+    ref = (sig[1] / sig[0]) * x.float() - ((1 - sig[1]) * (torch.exp(-h) - 1.0)) * x0
+    assert torch.equal(xg.cpu(), ref)
+
+
 def _pipeline(cfg, sd, sp):
     from omnivideo.configs import Config, t2v_1_3B
     from omnivideo.x2x_gen_unified_1_3B import OmniVideoX2XUnified1_3B
@@ -94,6 +131,32 @@ def test_generate_loop_matches_oracle(use_graph):
     ref = U.sample_loop(fc, fu, noise.clone(), steps, shift, guide)
     rel = float((lat.float().cpu() - ref.float()).norm() / ref.float().norm())
     assert rel < 2e-2, rel
+
+
+def test_generate_loop_dpmpp_matches_oracle():
+    """`generate(sample_solver="dpm++")` (x2x_gen_unified.py:417-426): float32 latents vs the oracle
+    DiT driven by the oracle DPM-Solver++ loop."""
+    cfg = syn.dit_config("tiny")
+    sd = syn.make_unified_state_dict(cfg, 0)
+    sdb = O.round_weights_bf16(sd)
+    sp = syn.make_special_tokens(cfg, 0)
+    text, text_null = syn.randn("in.text", (10, cfg["text_dim"]), 1), syn.randn("in.text_null", (6, cfg["text_dim"]), 1)
+    noise = syn.randn("gen.noise", (16, 3, 8, 12), 11).to(BF16)
+    pipe = _pipeline(cfg, sd, sp)
+    steps, shift, guide = 4, 5.0, 3.0
+    lat = pipe.generate("", precomputed_context=text.to(BF16), precomputed_context_null=text_null.to(BF16),
+                        size=(96, 64), frame_num=9, shift=shift, sample_solver="dpm++", sampling_steps=steps,
+                        guide_scale=guide, seed=1, noise=noise, return_latents=True)
+    assert lat.dtype == F32 and tuple(lat.shape) == (16, 3, 8, 12)
+    rbw = lambda t: t.to(BF16).float()
+    fc = lambda l, t: O.unified_forward(l.float(), t, sdb, cfg, 72, "bf16", text=rbw(text), special=sp)
+    fu = lambda l, t: O.unified_forward(l.float(), t, sdb, cfg, 72, "bf16", text=rbw(text_null), special=sp)
+    ref = D.sample_loop(fc, fu, noise.clone(), steps, shift, guide)
+    rel = float((lat.cpu() - ref).norm() / ref.norm())
+    assert rel < 2e-2, rel
+    with pytest.raises(NotImplementedError):
+        pipe.generate("", precomputed_context=text.to(BF16), precomputed_context_null=text_null.to(BF16),
+                      size=(96, 64), frame_num=9, sample_solver="euler", noise=noise, return_latents=True)
 
 
 def test_graph_replay_equals_eager_bitwise():

@@ -76,3 +76,51 @@ def test_unsupported_configurations_raise():
         P.FlowUniPCMultistepScheduler(solver_order=3)
     with pytest.raises(NotImplementedError):
         P.FlowUniPCMultistepScheduler(solver_type="bh1")
+
+
+# ---------------------------------------------------------------------------- DPM-Solver++
+
+def dpm_kernel_formula(row, guide, c, u, x, m1):
+    """What ovd_cfg_dpm_step computes per element (csrc/sampler.hip), in torch."""
+    from omnivideo.utils import fm_solvers as Q
+    v = u + guide * (c - u)
+    xs = x.float()
+    x0 = xs - row[Q.DP_SIGMA] * v
+    nxt = row[Q.DP_RATIO] * xs - row[Q.DP_B] * x0
+    if int(row[Q.DP_ORDER]) == 2:
+        nxt = nxt - row[Q.DP_HALF_B] * (row[Q.DP_INV_R0] * (x0 - m1))
+    return nxt, x0
+
+
+@pytest.mark.parametrize("steps", [20, 3, 1])
+def test_dpm_schedule_and_coefficient_table(golden_dir, steps):
+    from omnivideo.utils import fm_solvers as Q
+    from oracle import dpm as D
+    G = dict(np.load(os.path.join(golden_dir, "dpm.npz")))
+    s = Q.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    ts, n = Q.retrieve_timesteps(s, device="cpu", sigmas=Q.get_sampling_sigmas(steps, 5.0))
+    assert n == steps
+    if f"timesteps_{steps}_5" in G:
+        assert np.array_equal(ts.numpy(), G[f"timesteps_{steps}_5"])
+        assert np.array_equal(s.sigmas.numpy(), G[f"sigmas_{steps}_5"])
+    tab = Q.dpm_coefficients(s.sigmas, 2)
+    assert torch.isfinite(tab).all()
+    orc = D.DPMpp(steps, 5.0)
+    x = syn.randn("dpm.noise", (16, 2, 4, 6), 7).to(torch.bfloat16)
+    xo, m1 = x.clone(), torch.zeros(x.shape)
+    for i, t in enumerate(orc.timesteps):
+        c, u = linear_model(xo, t, "c"), linear_model(xo, t, "u")
+        nxt, m1 = dpm_kernel_formula(tab[i], 3.0, c, u, xo, m1)
+        xo = orc.step(u + 3.0 * (c - u), xo)
+        assert torch.equal(nxt, xo), i
+        assert torch.equal(xo, torch.from_numpy(G[f"traj_bf16_{steps}"][i]))
+
+
+def test_dpm_rejects_other_configurations():
+    from omnivideo.utils import fm_solvers as Q
+    with pytest.raises(NotImplementedError):
+        Q.FlowDPMSolverMultistepScheduler(solver_type="heun")
+    with pytest.raises(NotImplementedError):
+        Q.FlowDPMSolverMultistepScheduler(algorithm_type="sde-dpmsolver++")
+    with pytest.raises(ValueError):
+        Q.retrieve_timesteps(Q.FlowDPMSolverMultistepScheduler(), timesteps=[1], sigmas=[0.5])
