@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE decode leg")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: every rank uses cuda:0 and the gloo backend, to exercise the "
+                         "multi-rank control flow on a one-GPU box (numbers are meaningless)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -118,11 +121,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = "cpu" if args.rehearse_on_one_gpu else dev       # where the max-over-ranks reductions run
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend="gloo" if args.rehearse_on_one_gpu else "nccl", init_method="env://")
 
     from omnivideo import _hip as H
     from omnivideo.utils import synthetic as syn
@@ -171,7 +177,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         assert torch.isfinite(lat.float()).all(), "latents went non-finite"
@@ -211,7 +217,7 @@ def main():
             fence()
             vae_s = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([vae_s], device=dev, dtype=torch.float64)
+            tt = torch.tensor([vae_s], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             vae_s = float(tt.item())
         del vae
@@ -241,7 +247,7 @@ def main():
         if vae_s is not None:
             out["vae_decode_s_per_video"] = round(vae_s, 3)
             out["value_with_vae_decode"] = round(world * wl["frames"] / (wl["steps"] * ms_step * 1e-3 + vae_s), 4)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, wl, args.cpu_threads)
         print(json.dumps(out))
     if world > 1:
