@@ -159,6 +159,48 @@ def test_generate_loop_dpmpp_matches_oracle():
                       size=(96, 64), frame_num=9, sample_solver="euler", noise=noise, return_latents=True)
 
 
+def test_two_expert_switch_at_noise_boundary():
+    """The two-model pipeline (x2x_gen_unified.py:228-258,407): the high-noise expert serves the
+    steps with t >= 875, the low-noise expert the rest; both stay resident and each replays its
+    own captured graph.  Checked against the oracle loop switching weights at the same boundary."""
+    from omnivideo.configs import Config, t2v_A14B
+    from omnivideo.x2x_gen_unified import OmniVideoX2XUnified
+    cfg = syn.dit_config("tiny")
+    sds = [syn.make_unified_state_dict(cfg, seed) for seed in (0, 1)]
+    sp = syn.make_special_tokens(cfg, 0)
+    pipe = OmniVideoX2XUnified(Config(t2v_A14B), None, vlm_in_dim=cfg["vlm_in_dim"], use_visual_context_adapter=True,
+                               visual_context_adapter_patch_size=cfg["visual_patch_size"],
+                               max_context_len=cfg["text_len"], wan_config=dict(cfg))
+    assert pipe.high_noise_model is not pipe.low_noise_model
+    pipe.high_noise_model.load_state_dict(sds[0], strict=True)
+    pipe.low_noise_model.load_state_dict(sds[1], strict=True)
+    pipe.high_noise_model.to(BF16)
+    pipe.low_noise_model.to(BF16)
+    pipe.special_tokens = {k: v.cuda().to(BF16) for k, v in sp.items()}
+    text, text_null = syn.randn("in.text", (10, cfg["text_dim"]), 1), syn.randn("in.text_null", (6, cfg["text_dim"]), 1)
+    noise = syn.randn("gen.noise", (16, 3, 8, 12), 11).to(BF16)
+    steps, shift, guide = 6, 5.0, 3.0
+    _, ts = U.schedule(steps, shift)
+    n_high = int((ts >= 875).sum())
+    assert 0 < n_high < steps                   # the run really crosses the boundary
+    lat = pipe.generate("", precomputed_context=text.to(BF16), precomputed_context_null=text_null.to(BF16),
+                        size=(96, 64), frame_num=9, shift=shift, sampling_steps=steps, guide_scale=guide, seed=1,
+                        noise=noise, return_latents=True)
+    sdb = [O.round_weights_bf16(sd) for sd in sds]
+    rbw = lambda t: t.to(BF16).float()
+    pick = lambda t: sdb[0] if t >= 875 else sdb[1]
+    fc = lambda l, t: O.unified_forward(l.float(), t, pick(t), cfg, 72, "bf16", text=rbw(text), special=sp)
+    fu = lambda l, t: O.unified_forward(l.float(), t, pick(t), cfg, 72, "bf16", text=rbw(text_null), special=sp)
+    ref = U.sample_loop(fc, fu, noise.clone(), steps, shift, guide)
+    rel = float((lat.float().cpu() - ref.float()).norm() / ref.float().norm())
+    assert rel < 2e-2, rel
+    # one expert for every step gives a different answer: the switch is observable
+    one = U.sample_loop(lambda l, t: O.unified_forward(l.float(), t, sdb[1], cfg, 72, "bf16", text=rbw(text), special=sp),
+                        lambda l, t: O.unified_forward(l.float(), t, sdb[1], cfg, 72, "bf16", text=rbw(text_null),
+                                                       special=sp), noise.clone(), steps, shift, guide)
+    assert float((one.float() - ref.float()).norm() / ref.float().norm()) > 10 * rel
+
+
 def test_graph_replay_equals_eager_bitwise():
     cfg = syn.dit_config("tiny")
     sd, sp = syn.make_unified_state_dict(cfg, 0), syn.make_special_tokens(cfg, 0)
