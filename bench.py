@@ -36,6 +36,9 @@ WORKLOADS = {
                  frames=49, steps=50, text_len=6144, n_text=20, n_vlm=60, n_null=126, visual=False),
     "cfg3": dict(desc="OmniVideo2-1.3B V2V 49f 832x480 40 steps bf16", model="1.3B", latent=(16, 13, 60, 104),
                  frames=49, steps=40, text_len=6272, n_text=550, n_vlm=700, n_null=126, visual=True),
+    "cfg4": dict(desc="OmniVideo2-A14B T2V 81f 1280x720 50 steps bf16 (one expert resident in the bench)", model="A14B",
+                 latent=(16, 21, 90, 160), frames=81, steps=50, text_len=6144, n_text=20, n_vlm=60, n_null=126,
+                 visual=False),
     "cfg1": dict(desc="OmniVideo2-1.3B T2V 17f 256x256 20 steps (bf16 on GPU)", model="1.3B", latent=(16, 5, 32, 32),
                  frames=17, steps=20, text_len=512, n_text=20, n_vlm=60, n_null=126, visual=False),
 }
