@@ -2,8 +2,11 @@
 // channel vector is contiguous (coalesced 16-byte loads into LDS, 128-byte coalesced
 // stores of 32 output channels per voxel).
 //
-// conv3d_cl_kernel is an implicit GEMM on the matrix cores in exact fp32
-// (v_mfma_f32_32x32x2_f32: an fmaf chain, no reduced-precision inputs):
+// conv3d_cl_kernel is an implicit GEMM on the matrix cores, fp32 in and out.  Products run
+// either as split bf16 (default: each operand = bf16 hi + bf16 lo, three
+// v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation, ~2^-16 relative error: finer than
+// the TF32 convolutions the reference's fp32 VAE gets from cuDNN by default) or in exact fp32
+// (v_mfma_f32_32x32x2_f32: an fmaf chain; OVD_VAE_EXACT_FP32=1):
 //   out[t,h,w,co] = bias[co] + sum_{kt,kh,kw,ci} act(in[t*st+kt-pt, h*s+kh-ph, w*s+kw-ph, ci]) * W[kt,kh,kw][co][ci]
 // One workgroup = 4 waves = 128 output voxels (an 8x16 patch of one frame, or 128
 // consecutive voxels for 1x1 kernels) x 32*NB output channels.  Per (kt, 32-channel
@@ -34,7 +37,31 @@ struct ConvArgs {
     float norm_scale;                    // sqrt(Cin) when gamma != null
 };
 
-template <int NB>
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits in two bf16 values
+__device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
+    hi = f2bf(x);
+    lo = f2bf(x - bf2f(hi));
+}
+// four floats -> 4 hi + 4 lo bf16, stored at p (hi) and p + 64 bytes (lo)
+__device__ __forceinline__ void store_split4(char* p, const float4& v) {
+    uint32_t h[4], l[4];
+    split_bf16(v.x, h[0], l[0]);
+    split_bf16(v.y, h[1], l[1]);
+    split_bf16(v.z, h[2], l[2]);
+    split_bf16(v.w, h[3], l[3]);
+    *reinterpret_cast<uint2*>(p) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    *reinterpret_cast<uint2*>(p + 64) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
+// SPLIT = false: exact fp32 products (v_mfma_f32_32x32x2_f32).  SPLIT = true: both operands are
+// split into bf16 hi + lo while they are staged into LDS (same 144-byte rows: 32 hi | 32 lo | pad)
+// and each product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+// ~2^-16 relative error per product at 3/16 of the fp32 matrix time.
+template <int NB, bool SPLIT>
 __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* halo = lds;                          // [HR*WR][LDV]
@@ -94,12 +121,12 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
                         val.x = val.x * r * g.x; val.y = val.y * r * g.y;
                         val.z = val.z * r * g.z; val.w = val.w * r * g.w;
                     }
-                    if (a.silu) {
-                        val.x = val.x / (1.f + expf(-val.x)); val.y = val.y / (1.f + expf(-val.y));
-                        val.z = val.z / (1.f + expf(-val.z)); val.w = val.w / (1.f + expf(-val.w));
+                    if (a.silu) {       // x * sigmoid(x) from one v_exp_f32 and one v_rcp_f32 (~2 ulp)
+                        val.x = silu_f(val.x); val.y = silu_f(val.y); val.z = silu_f(val.z); val.w = silu_f(val.w);
                     }
                 }
-                *reinterpret_cast<float4*>(halo + v * LDV + 4 * j) = val;
+                if (SPLIT) store_split4(reinterpret_cast<char*>(halo + v * LDV) + 8 * j, val);
+                else *reinterpret_cast<float4*>(halo + v * LDV + 4 * j) = val;
             }
             const int ksteps = (min(32, a.Cin - cc * 32) + 7) >> 3;
             for (int kh = 0; kh < a.KH; ++kh)
@@ -112,7 +139,8 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
                         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (co < a.Cout && ci < a.Cin)
                             val = *reinterpret_cast<const float4*>(a.w + ((long)tap * a.Cout + co) * a.Cin + ci);
-                        *reinterpret_cast<float4*>(wt + r * LDV + 4 * j) = val;
+                        if (SPLIT) store_split4(reinterpret_cast<char*>(wt + r * LDV) + 8 * j, val);
+                        else *reinterpret_cast<float4*>(wt + r * LDV + 4 * j) = val;
                     }
                     __syncthreads();
                     int hsrc, wsrc;
@@ -120,6 +148,25 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
                     else { hsrc = dh * a.s + kh; wsrc = dw * a.s + kw; }
                     const float* ap = halo + (hsrc * WR + wsrc) * LDV + 4 * kq;
                     const float* bp = wt + (lane & 31) * LDV + 4 * kq;
+                    if (SPLIT) {
+                        // lane (row/col = lane & 31, half kq) feeds k = 16*ks + 8*kq .. +7: 16 bytes
+                        // at +32*ks + 16*kq of the hi plane, the lo plane 64 bytes further
+                        const char* ac = reinterpret_cast<const char*>(ap);
+                        const char* bc = reinterpret_cast<const char*>(bp);
+                        const int k16 = (ksteps + 1) >> 1;
+                        for (int ks = 0; ks < k16; ++ks) {
+                            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ac + 32 * ks);
+                            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ac + 64 + 32 * ks);
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) {
+                                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bc + nb * 32 * LDV * 4 + 32 * ks);
+                                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bc + nb * 32 * LDV * 4 + 64 + 32 * ks);
+                                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nb], 0, 0, 0);
+                                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nb], 0, 0, 0);
+                                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nb], 0, 0, 0);
+                            }
+                        }
+                    } else
                     for (int k8 = 0; k8 < ksteps; ++k8) {
                         const float4 av = *reinterpret_cast<const float4*>(ap + 8 * k8);
                         const float avv[4] = {av.x, av.y, av.z, av.w};
@@ -281,21 +328,40 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
     if (upsample2) { HR = TH / 2 + 2; WR = TW / 2 + 2; }
     else { HR = (TH - 1) * stride_hw + KH; WR = (TW - 1) * stride_hw + KW; }
     OVD_REQUIRE(HR * WR <= MAX_HALO, "conv3d: halo too large");
-    const int nb = Cout > 96 ? 4 : (Cout > 32 ? 3 : 1);
+    // 32*nb output channels per workgroup, nb in {4, 3, 1}: least padding, then the widest
+    int nb = 1;
+    {
+        int best = 1 << 30;
+        const int cand[3] = {4, 3, 1};
+        for (int i = 0; i < 3; ++i) {
+            const int waste = ceil_div(Cout, 32 * cand[i]) * 32 * cand[i] - Cout;
+            if (waste < best) { best = waste; nb = cand[i]; }
+        }
+    }
     const size_t lds = (size_t)(HR * WR + 32 * nb) * LDV * sizeof(float);
     dim3 grid(tiles, ceil_div(Cout, 32 * nb)), blk(256);
-#define CONV_CASE(NBV)                                                                                         \
+    // split-bf16 products by default; OVD_VAE_EXACT_FP32=1 selects the exact fp32 matrix path
+    static int exact = -1;
+    if (exact < 0) {
+        const char* e = getenv("OVD_VAE_EXACT_FP32");
+        exact = (e && atoi(e) != 0) ? 1 : 0;
+    }
+#define CONV_CASE(NBV, SPL)                                                                                    \
     case NBV: {                                                                                                \
         static size_t cur = 0;                                                                                 \
         if (lds > cur) {                                                                                       \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_cl_kernel<NBV>),                     \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_cl_kernel<NBV, SPL>),                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)       \
                 OVD_FAIL("conv3d: cannot reserve %zu bytes of LDS", lds);                                      \
             cur = lds;                                                                                         \
         }                                                                                                      \
-        hipLaunchKernelGGL(conv3d_cl_kernel<NBV>, grid, blk, lds, st, a);                                      \
+        hipLaunchKernelGGL((conv3d_cl_kernel<NBV, SPL>), grid, blk, lds, st, a);                               \
     } break;
-    switch (nb) { CONV_CASE(1) CONV_CASE(3) CONV_CASE(4) }
+    if (exact) {
+        switch (nb) { CONV_CASE(1, false) CONV_CASE(3, false) CONV_CASE(4, false) }
+    } else {
+        switch (nb) { CONV_CASE(1, true) CONV_CASE(3, true) CONV_CASE(4, true) }
+    }
 #undef CONV_CASE
     OVD_CHECK_LAUNCH("conv3d_cl");
     return 0;
