@@ -265,8 +265,10 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
 
 // True when the shape fits this kernel (the caller falls back to the 128 x 128 kernel otherwise).
 bool ovd_gemm256_applicable(long lda, long ldw, int M, int N, int K) {
-    return N % TN == 0 && K % TK == 0 && K >= 3 * TK && M >= 2 * TM && (long)M * lda * 2 < (1L << 32) &&
-           (long)N * ldw * 2 < (1L << 32);
+    // one workgroup per CU: worth it from about two rounds of 256 x 256 tiles over the 256 CUs
+    const long tiles = (long)ceil_div(M, TM) * (N / TN);
+    return N % TN == 0 && K % TK == 0 && K >= 3 * TK && M >= 2 * TM && tiles >= 512 &&
+           (long)M * lda * 2 < (1L << 32) && (long)N * ldw * 2 < (1L << 32);
 }
 
 int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, const bf16_t* bias, void* out,

@@ -108,8 +108,9 @@ def test_rmsnorm_rope_batched_and_offset(H):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 128, 64), (130, 256, 192), (300, 384, 1536), (257, 1536, 8960),
-                                   # M >= 512 with N % 256 == 0: the 256 x 256 ring-pipelined kernel
-                                   (777, 256, 128), (1100, 512, 1536), (513, 1536, 192), (1024, 768, 4480)])
+                                   (777, 256, 128), (1100, 512, 1536),
+                                   # >= 512 tiles of 256 x 256: the ring-pipelined large-shape kernel
+                                   (8192, 4096, 128), (4999, 6656, 192), (16500, 2048, 320)])
 def test_gemm_epilogues(H, M, N, K):
     a = rb(syn.randn("g.a", (M, K), 3))
     w = rb(syn.uniform("g.w", (N, K), 1 / math.sqrt(K), 3))
@@ -120,7 +121,9 @@ def test_gemm_epilogues(H, M, N, K):
     H.gemm(A, W, out, B, H.EPI_BF16)
     assert_bf16_close(out, acc, ulps=1.01, atol=2e-4)
     H.gemm(A, W, out, B, H.EPI_BF16_GELU)
-    assert_bf16_close(out, O.gelu_tanh(rb(acc)), ulps=2.01, atol=2e-3)
+    # the pre-activation is rounded to bf16 before GELU: where the fp32 sum sits on a rounding
+    # tie (different summation order) the input moves by one bf16 ulp, so does the output
+    assert_bf16_close(out, O.gelu_tanh(rb(acc)), ulps=2.01, atol=2e-3, flip_frac=2e-4, flip_atol=4e-2)
     o32 = torch.empty(M, N, device="cuda")
     H.gemm(A, W, o32, B, H.EPI_F32)
     assert_bf16_close(o32, acc, ulps=1.01, atol=2e-4)
