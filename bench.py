@@ -200,9 +200,14 @@ def main():
             flops_launch = 4.0 * L * L * cfg["dim"] * 2            # batch of 2 guidance branches
             avg_ms = sum(ms) / len(ms)
             ach = flops_launch / (avg_ms * 1e-3) / 1e12
+            # HBM-side bytes per launch cannot be counted from here: they come from separate
+            # rocprofv3 --pmc passes over the same kernel at the cfg2 shape, kept under profiles/
+            traffic, tpath = None, os.path.join(ROOT, "profiles", "r1_attn_self_pmc_traffic.json")
+            if args.workload in ("cfg2", "cfg3") and os.path.exists(tpath):
+                traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
             roof = {"bound": "mfma", "kernel": "attn_pipe_kernel_w8 (self-attention)", "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4),
+                    "traffic": traffic, "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4),
                     "flop_per_launch": flops_launch}
 
     # ---- VAE decode of one video's latent (random-init full-width VAE), reported beside the loop

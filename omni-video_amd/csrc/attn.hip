@@ -229,12 +229,29 @@ template <int NW>
 __device__ __forceinline__ void
 attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
               bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,
-              long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias) {
+              long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias, int n_qblocks,
+              int n_heads, int n_batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2] | V[2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+    // 1-D grid over (query block, head, batch).  Workgroup ids go round-robin over the 8 XCDs, each
+    // with its own L2: when the (batch, head) pairs divide by 8, pair p is served entirely by
+    // XCD p % 8 - consecutive workgroups of that XCD walk its query blocks - so a head's K/V
+    // stream is fetched into one L2 instead of eight.
+    int qb, pair;
+    {
+        const int id = blockIdx.x, pairs = n_heads * n_batch;
+        if ((pairs & 7) == 0) {
+            const int j = id >> 3;
+            pair = (id & 7) + 8 * (j / n_qblocks);
+            qb = j % n_qblocks;
+        } else {
+            pair = id / n_qblocks;
+            qb = id % n_qblocks;
+        }
+    }
+    const int head = pair % n_heads, b = pair / n_heads;
+    const int q0 = qb * (32 * NW) + wave * 32;
 
     const bf16_t* Qb = Q + b * q_bs + (long)head * HD;
     const bf16_t* Kb = K + b * k_bs + (long)head * HD;
@@ -359,9 +376,10 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
     __global__ void __launch_bounds__(64 * NW, 2) attn_pipe_kernel_w##NW(                                \
         const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,       \
         bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,   \
-        long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias) {                 \
+        long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias, int n_qblocks,    \
+        int n_heads, int n_batch) {                                                                      \
         attn_fwd_pipe<NW>(Q, K, V, O, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs,     \
-                          scale_log2, tail_bias);                                                        \
+                          scale_log2, tail_bias, n_qblocks, n_heads, n_batch);                           \
     }
 ATTN_KERNEL(4)
 ATTN_KERNEL(8)
@@ -408,9 +426,11 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
                 OVD_FAIL("attention: cannot reserve %zu bytes of LDS", lds);                                \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        dim3 grid(ceil_div(Lq, 32 * NW), N, B), blk(64 * NW);                                              \
+        const int nqb = ceil_div(Lq, 32 * NW);                                                             \
+        OVD_REQUIRE((long)nqb * N * B < (1L << 31), "attention: grid too large");                          \
+        dim3 grid(nqb * N * B), blk(64 * NW);                                                              \
         hipLaunchKernelGGL(KERNEL, grid, blk, lds, st, q, k, v, out, Lq, Lk, k_len, q_ld, k_ld, v_ld,      \
-                           o_ld, q_bs, k_bs, v_bs, o_bs, scale_log2, tail_bias);                           \
+                           o_ld, q_bs, k_bs, v_bs, o_bs, scale_log2, tail_bias, nqb, N, B);                \
     }
     if (waves == 8) ATTN_CASE(attn_pipe_kernel_w8, 8) else ATTN_CASE(attn_pipe_kernel_w4, 4)
 #undef ATTN_CASE
