@@ -52,9 +52,13 @@ def attn(B, Lq, Lk, N, k_len=None, check=False, strided_q=False, fused_kv=False,
     print(msg, flush=True)
 
 
-def gemm(M, N, K, epi=0, check=False):
-    a = torch.randn(M, K, device="cuda").to(BF16)
-    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF16)
+def gemm(M, N, K, epi=0, check=False, uniform=False):
+    if uniform:     # operands uniform in [-1, 1): the distribution published GEMM numbers are quoted on
+        a = (torch.rand(M, K, device="cuda") * 2 - 1).to(BF16)
+        w = (torch.rand(N, K, device="cuda") * 2 - 1).to(BF16)
+    else:
+        a = torch.randn(M, K, device="cuda").to(BF16)
+        w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF16)
     b = torch.randn(N, device="cuda").to(BF16)
     out = torch.empty(M, N, device="cuda", dtype=BF16 if epi < 2 else torch.float32)
     if epi >= 2:
@@ -118,6 +122,10 @@ if __name__ == "__main__":
         gemm(777, 256, 192, 3, check=True)
         gemm(4096, 1536, 1536, 1, check=True)
         gemm(40560, 1536, 1536, 2, check=True)
+    if "gemmsq" in args.what:
+        gemm(4096, 4096, 4096, 0, uniform=True)
+        gemm(8192, 8192, 8192, 0, uniform=True)
+        gemm(8192, 8192, 8192, 0)
     if "gemm" in args.what:
         M = 40560
         gemm(M, 4608, 1536, 0)      # fused QKV
