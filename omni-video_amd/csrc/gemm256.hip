@@ -131,7 +131,7 @@ template <int EPI, int PHASES>
 __global__ void __launch_bounds__(512, 2)
 gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
                const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
-               int M, int N, int K, int tiles_m, int tiles_n) {
+               int M, int N, int K, int tiles_m, int tiles_n, int GM) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,7 +145,6 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    constexpr int GM = 4;
     const int per_group = GM * tiles_n;
     const int grp = bid / per_group;
     const int first_m = grp * GM;
@@ -287,8 +286,14 @@ int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, 
             attr_set = true;                                                                              \
         }                                                                                                 \
         hipLaunchKernelGGL((gemm256_kernel<E, PH>), grid, blk, lds, st, A, lda, W, ldw, bias, out, ldo, gate, \
-                           M, N, K, tiles_m, tiles_n);                                                    \
+                           M, N, K, tiles_m, tiles_n, gm);                                                \
     } break;
+    // tile-rows per group of the tile walk (OVD_GEMM_GM overrides: tuning aid)
+    static int gm = -1;
+    if (gm < 0) {
+        const char* e = getenv("OVD_GEMM_GM");
+        gm = (e && atoi(e) > 0) ? atoi(e) : 4;
+    }
     static int phases = -1;
     if (phases < 0) {
         const char* e = getenv("OVD_GEMM_PHASES");
