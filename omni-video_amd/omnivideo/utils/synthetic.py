@@ -195,3 +195,47 @@ def make_vae_state_dict(cfg, seed=0):
     sd["decoder.head.0.gamma"] = 1.0 + randn("decoder.head.0.gamma", (ddims[-1], 1, 1, 1), seed, 0.1)
     _conv(sd, "decoder.head.2", 3, ddims[-1], (3, 3, 3), seed)
     return sd
+
+
+# ---------------------------------------------------------------------------- umT5 text encoder
+
+def t5_config(name="umt5-xxl", **over):
+    """Encoder hyper-parameters (reference: omnivideo/modules/t5.py:455-468)."""
+    if name == "umt5-xxl":
+        base = dict(vocab_size=256384, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64, num_layers=24,
+                    num_buckets=32)
+    elif name == "tiny":
+        base = dict(vocab_size=300, dim=256, dim_attn=256, dim_ffn=512, num_heads=4, num_layers=2, num_buckets=32)
+    else:
+        raise KeyError(name)
+    base.update(over)
+    return base
+
+
+def make_t5_state_dict(cfg, seed=0):
+    """Parameter names of the reference's T5Encoder with shared_pos=False (t5.py:266-311)."""
+    sd = {}
+    d, da, df = cfg["dim"], cfg["dim_attn"], cfg["dim_ffn"]
+    sd["token_embedding.weight"] = randn("t5.token_embedding", (cfg["vocab_size"], d), seed)
+    for i in range(cfg["num_layers"]):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"] = 1.0 + randn("t5." + p + "norm1", (d,), seed, 0.1)
+        for n_ in ("q", "k", "v"):
+            sd[p + f"attn.{n_}.weight"] = randn("t5." + p + n_, (da, d), seed, (d * (da // cfg["num_heads"])) ** -0.25
+                                                if n_ != "v" else d ** -0.5)
+        sd[p + "attn.o.weight"] = randn("t5." + p + "o", (d, da), seed, da ** -0.5)
+        sd[p + "norm2.weight"] = 1.0 + randn("t5." + p + "norm2", (d,), seed, 0.1)
+        sd[p + "ffn.gate.0.weight"] = randn("t5." + p + "gate", (df, d), seed, d ** -0.5)
+        sd[p + "ffn.fc1.weight"] = randn("t5." + p + "fc1", (df, d), seed, d ** -0.5)
+        sd[p + "ffn.fc2.weight"] = randn("t5." + p + "fc2", (d, df), seed, df ** -0.5)
+        sd[p + "pos_embedding.embedding.weight"] = randn("t5." + p + "pos", (cfg["num_buckets"], cfg["num_heads"]),
+                                                         seed, 0.5)
+    sd["norm.weight"] = 1.0 + randn("t5.norm", (d,), seed, 0.1)
+    return sd
+
+
+def make_t5_ids(cfg, batch, length, lens, seed=0):
+    """Token ids [batch, length] and the prefix mask the tokenizer would return (1 = real token)."""
+    ids = torch.from_numpy(_rng(seed, "t5.ids").integers(0, cfg["vocab_size"], size=(batch, length)))
+    mask = (torch.arange(length)[None, :] < torch.tensor(lens)[:, None]).long()
+    return ids * mask, mask

@@ -4,7 +4,7 @@ modules (loaded by oracle/ref_loader.py from /root/reference) on CPU in float32.
 Only outputs are stored: weights and inputs are regenerated from their names by
 omnivideo.utils.synthetic, so the fixtures stay small.  Run from the repo root:
 
-    python oracle/gen_golden.py [dit] [unipc] [dpm] [vae]
+    python oracle/gen_golden.py [dit] [unipc] [dpm] [t5] [vae]
 
 The reference tree exists only in the build container; the committed .npz files are
 what travels.
@@ -156,8 +156,29 @@ def gen_dpm():
     print("dpm.npz:", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def gen_t5():
+    """Outputs of the reference T5Encoder (tiny configuration, shared_pos=False, eval mode) in
+    float32 and with the module cast to bf16, for two batches of token ids."""
+    ns = ref_loader.load()
+    cfg = syn.t5_config("tiny")
+    sd = syn.make_t5_state_dict(cfg, 0)
+    out = {}
+    for name, (B, L, lens) in {"short": (2, 40, [40, 23]), "long": (1, 300, [277])}.items():
+        ids, mask = syn.make_t5_ids(cfg, B, L, lens, seed=3)
+        for dt_name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            m = ns.t5.T5Encoder(vocab=cfg["vocab_size"], dim=cfg["dim"], dim_attn=cfg["dim_attn"],
+                                dim_ffn=cfg["dim_ffn"], num_heads=cfg["num_heads"], num_layers=cfg["num_layers"],
+                                num_buckets=cfg["num_buckets"], shared_pos=False, dropout=0.1)
+            m.load_state_dict(sd, strict=True)
+            m = m.to(dt).eval()
+            with torch.no_grad():
+                out[f"{name}_{dt_name}"] = m(ids, mask).float().numpy()
+    np.savez_compressed(os.path.join(GOLD, "t5_tiny.npz"), **out)
+    print("t5_tiny.npz:", {k: tuple(v.shape) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dit", "unipc", "dpm", "vae"]
+    which = sys.argv[1:] or ["dit", "unipc", "dpm", "t5", "vae"]
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     if "dit" in which:
@@ -166,6 +187,8 @@ if __name__ == "__main__":
         gen_unipc()
     if "dpm" in which:
         gen_dpm()
+    if "t5" in which:
+        gen_t5()
     if "vae" in which:
         from oracle import gen_golden_vae
         gen_golden_vae.main()

@@ -142,7 +142,7 @@ def _load(subdir, fname, modname):
 @functools.lru_cache(maxsize=None)
 def load():
     """Returns a namespace with the reference's hot-path modules:
-    .model .attention .unified_model .visual_context_adapter .vae2_1 .unipc .dpm"""
+    .model .attention .unified_model .visual_context_adapter .vae2_1 .unipc .dpm .t5"""
     if not available():
         raise RuntimeError(f"reference tree not found at {REF_ROOT}")
     _install_stubs()
@@ -162,4 +162,17 @@ def load():
     ns.vae2_1 = _load("modules", "vae2_1.py", "vae2_1")
     ns.unipc = _load("utils", "fm_solvers_unipc.py", "fm_solvers_unipc")
     ns.dpm = _load("utils", "fm_solvers.py", "fm_solvers")
+    # t5.py evaluates torch.cuda.current_device() as a default argument at class-definition time
+    # (t5.py:477), which raises on a CPU-only box; answer 0 while the module is being loaded.  Its
+    # `from .tokenizers import ...` needs ftfy: a stub module stands in (the tokenizer is not used).
+    import torch.cuda as _tc
+    _saved = _tc.current_device
+    _tc.current_device = lambda: 0
+    tok = types.ModuleType(f"{_PKG}.modules.tokenizers")
+    tok.HuggingfaceTokenizer = None
+    sys.modules.setdefault(f"{_PKG}.modules.tokenizers", tok)
+    try:
+        ns.t5 = _load("modules", "t5.py", "t5")
+    finally:
+        _tc.current_device = _saved
     return ns
