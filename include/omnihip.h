@@ -160,6 +160,26 @@ int ovd_cfg_dpm_step(const float* cond, const float* uncond, const void* sample,
                      int sample_is_bf16, void* stream);
 #define OVD_DPM_COEF_STRIDE 8
 
+/* umT5 encoder self-attention (omnivideo/modules/t5.py:85-119): no score scaling, additive
+ * relative-position bias, fp32 softmax, bf16 tensors between the steps:
+ *   s = bf16(bf16(q.k) + pos_embedding[bucket[i][j]][head]);  keys j >= k_lens[b] get the lowest score
+ *   p = bf16(softmax_fp32(s));  out = bf16(p.v)
+ * qkv [B, L, 3*N*64] bf16 (q | k | v; ld = elements between tokens), pos_embedding [buckets, N]
+ * bf16 (the block's T5RelativeEmbedding weight, t5.py:230), bucket [L, L] int32 (t5.py:244-263,
+ * built once per length on the host), k_lens [B] int32 or NULL (prefix mask lengths), out
+ * [B, L, N*64] bf16.  head_dim must be 64. */
+int ovd_t5_attention_bf16(const uint16_t* qkv, int64_t ld, const uint16_t* pos_embedding, const int32_t* bucket,
+                          const int32_t* k_lens, uint16_t* out, int64_t ldo, int B, int L, int N, int head_dim,
+                          void* stream);
+
+/* out[m][f] = bf16(fc1[m][f] * GELU(gate[m][f])) with h = [gate | fc1] ([M, 2F] bf16, the fused
+ * output of both projections); GELU is the reference's tensor-op formula evaluated in bf16
+ * arithmetic (t5.py:47-49, :135-136). */
+int ovd_t5_gated_gelu_bf16(const uint16_t* h, int64_t ldh, uint16_t* out, int64_t ldo, int M, int F, void* stream);
+
+/* x = bf16(x + y) over n (even) elements: the encoder's bf16 residual adds (t5.py:172-173). */
+int ovd_add_bf16(uint16_t* x, const uint16_t* y, int64_t n, void* stream);
+
 /* *step_ptr += 1 on the device (advances the step counter inside a captured graph). */
 int ovd_step_advance(int* step_ptr, void* stream);
 

@@ -23,6 +23,10 @@ int ovd_impl_gemm_bf16(const bf16_t*, long, const bf16_t*, long, const bf16_t*, 
                        int, int, hipStream_t);
 int ovd_impl_attn_fwd(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, long, long,
                       long, long, long, long, long, long, float, int, hipStream_t);
+int ovd_impl_t5_attention(const bf16_t*, long, const bf16_t*, const int*, const int*, bf16_t*, long, int, int, int, int,
+                          hipStream_t);
+int ovd_impl_t5_gated_gelu(const bf16_t*, long, bf16_t*, long, int, int, hipStream_t);
+int ovd_impl_add_bf16(bf16_t*, const bf16_t*, long, hipStream_t);
 int ovd_impl_patchify(const void*, int, bf16_t*, int, int, int, int, int, int, int, hipStream_t);
 int ovd_impl_time_sinusoid(const double*, const int*, int, float*, int, hipStream_t);
 int ovd_impl_gemv_f32(const float*, const bf16_t*, const bf16_t*, float*, int, int, int, hipStream_t);
@@ -156,6 +160,23 @@ int ovd_cfg_dpm_step(const float* cond, const float* uncond, const void* sample,
     OVD_REQUIRE(step_ptr != nullptr || step >= 0, "cfg_dpm: negative step");
     return ovd_impl_cfg_dpm_step(cond, uncond, sample, next, m1, coef, guide_scale, step_ptr, step, n,
                                  sample_is_bf16, ST(stream));
+}
+
+int ovd_t5_attention_bf16(const uint16_t* qkv, int64_t ld, const uint16_t* pos_embedding, const int32_t* bucket,
+                          const int32_t* k_lens, uint16_t* out, int64_t ldo, int B, int L, int N, int head_dim,
+                          void* stream) {
+    NONNULL(qkv); NONNULL(pos_embedding); NONNULL(bucket); NONNULL(out);
+    return ovd_impl_t5_attention(qkv, ld, pos_embedding, bucket, k_lens, out, ldo, B, L, N, head_dim, ST(stream));
+}
+
+int ovd_t5_gated_gelu_bf16(const uint16_t* h, int64_t ldh, uint16_t* out, int64_t ldo, int M, int F, void* stream) {
+    NONNULL(h); NONNULL(out);
+    return ovd_impl_t5_gated_gelu(h, ldh, out, ldo, M, F, ST(stream));
+}
+
+int ovd_add_bf16(uint16_t* x, const uint16_t* y, int64_t n, void* stream) {
+    NONNULL(x); NONNULL(y);
+    return ovd_impl_add_bf16(x, y, n, ST(stream));
 }
 
 int ovd_step_advance(int* step_ptr, void* stream) {

@@ -29,6 +29,9 @@ SIGNATURES = {
     "ovd_head_unpatchify": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_cfg_unipc_step": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
     "ovd_cfg_dpm_step": [_p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
+    "ovd_t5_attention_bf16": [_p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p],
+    "ovd_t5_gated_gelu_bf16": [_p, _l, _p, _l, _i, _i, _p],
+    "ovd_add_bf16": [_p, _p, _l, _p],
     "ovd_step_advance": [_p, _p],
     "ovd_vae_conv3d_f32": [_p] * 7 + [_i] + [_p] * 4 + [_i] * 14 + [_p],
     "ovd_vae_voxel_rnorm": [_p, _p, _l, _i, _p],
@@ -257,6 +260,39 @@ def cfg_dpm_step(cond, uncond, sample, nxt, m1, coef, guide_scale, step=0, step_
     _call("ovd_cfg_dpm_step", _ptr(cond, F32), _ptr(uncond, F32), _ptr(sample), _ptr(nxt, F32), _ptr(m1, F32),
           _ptr(coef, F32), float(guide_scale), _ptr(step_ptr, torch.int32, True), int(step), n,
           int(sample.dtype == BF16), _stream())
+
+
+def t5_attention(qkv, pos_embedding, bucket, k_lens, out, num_heads):
+    """qkv [B, L, 3*N*64] bf16, pos_embedding [buckets, N] bf16, bucket [L, L] int32, k_lens [B] int32
+    or None, out [B, L, N*64] bf16."""
+    B, L, W = qkv.shape
+    if W != 3 * num_heads * 64 or qkv.stride(2) != 1 or qkv.stride(0) != L * qkv.stride(1):
+        raise ValueError("t5 attention: qkv must be [B, L, 3*N*64] with dense rows")
+    if tuple(out.shape) != (B, L, num_heads * 64) or not out.is_contiguous():
+        raise ValueError("t5 attention: out must be contiguous [B, L, N*64]")
+    if tuple(bucket.shape) != (L, L) or bucket.dtype != torch.int32 or not bucket.is_contiguous():
+        raise ValueError("t5 attention: bucket must be contiguous int32 [L, L]")
+    if pos_embedding.shape[1] != num_heads or not pos_embedding.is_contiguous():
+        raise ValueError("t5 attention: pos_embedding must be contiguous [buckets, N]")
+    _call("ovd_t5_attention_bf16", _ptr(qkv, BF16), qkv.stride(1), _ptr(pos_embedding, BF16), _ptr(bucket, torch.int32),
+          _ptr(k_lens, torch.int32, True), _ptr(out, BF16), out.stride(1), B, L, num_heads, 64, _stream())
+    return out
+
+
+def t5_gated_gelu(h, out):
+    M, F2, ldh = _rows(h)
+    Mo, F, ldo = _rows(out)
+    if Mo != M or F2 != 2 * F:
+        raise ValueError("t5 gated gelu: h must be [M, 2F] and out [M, F]")
+    _call("ovd_t5_gated_gelu_bf16", _ptr(h, BF16), ldh, _ptr(out, BF16), ldo, M, F, _stream())
+    return out
+
+
+def add_bf16(x, y):
+    if x.shape != y.shape or not x.is_contiguous() or not y.is_contiguous():
+        raise ValueError("add_bf16: tensors must be contiguous and equally shaped")
+    _call("ovd_add_bf16", _ptr(x, BF16), _ptr(y, BF16), x.numel(), _stream())
+    return x
 
 
 def step_advance(step_ptr):

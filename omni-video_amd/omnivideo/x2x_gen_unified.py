@@ -10,10 +10,10 @@ What changes underneath, with unchanged arithmetic per element:
     replayed; the step index lives on the device, so the loop has no host
     synchronisation (the reference syncs on `t.item()` every step, :235);
   * both experts stay resident in HBM (288 GB): no CPU offload round trips.
-Out of the accelerated path and therefore not provided here: the umT5 text encoder and
-FSDP sharding.  Text conditions come in as tensors (`precomputed_context`, and
-`precomputed_context_null` for the negative prompt), or through a user-supplied
-`self.text_encoder` callable with the reference's `(texts, device) -> list[Tensor]`
+Not provided: FSDP sharding.  The umT5 text encoder (modules/t5.py) is attached when
+`checkpoint_dir` holds its checkpoint and tokenizer files; otherwise text conditions come in as
+tensors (`precomputed_context`, and `precomputed_context_null` for the negative prompt), or
+through any `self.text_encoder` callable with the reference's `(texts, device) -> list[Tensor]`
 convention.
 """
 import logging
@@ -108,7 +108,7 @@ class OmniVideoX2XUnified:
         self.boundary = config.get("boundary", 0.875)
         self.param_dtype = config.param_dtype
         self.vae_stride, self.patch_size = config.vae_stride, config.patch_size
-        self.text_encoder = None        # see module docstring
+        self.text_encoder = self._build_text_encoder(config, checkpoint_dir)     # None without its files
         self.vae = self._build_vae(os.path.join(checkpoint_dir, config.vae_checkpoint) if checkpoint_dir else None)
         self._init_sequence_parallel(use_usp, sp_size)
         self._build_models(wan_config, checkpoint_dir, vlm_in_dim, use_visual_context_adapter,
@@ -120,6 +120,19 @@ class OmniVideoX2XUnified:
         self.use_graph = True
 
     # ------------------------------------------------------------------ construction helpers
+    def _build_text_encoder(self, config, checkpoint_dir):
+        """reference :79-86: umT5-XXL from `t5_checkpoint` / `t5_tokenizer` under checkpoint_dir."""
+        if not checkpoint_dir:
+            return None
+        ckpt = os.path.join(checkpoint_dir, config.t5_checkpoint)
+        tok = os.path.join(checkpoint_dir, config.t5_tokenizer)
+        if not (os.path.exists(ckpt) and os.path.isdir(tok)):
+            logging.info("no umT5 checkpoint/tokenizer under checkpoint_dir: pass precomputed_context tensors")
+            return None
+        from .modules.t5 import T5EncoderModel
+        return T5EncoderModel(text_len=config.text_len, dtype=config.t5_dtype, device=self.device,
+                              checkpoint_path=ckpt, tokenizer_path=tok)
+
     def _build_vae(self, vae_pth):
         try:
             from .modules.vae2_1 import Wan2_1_VAE

@@ -124,3 +124,23 @@ def test_dpm_rejects_other_configurations():
         Q.FlowDPMSolverMultistepScheduler(algorithm_type="sde-dpmsolver++")
     with pytest.raises(ValueError):
         Q.retrieve_timesteps(Q.FlowDPMSolverMultistepScheduler(), timesteps=[1], sigmas=[0.5])
+
+
+# ---------------------------------------------------------------------------- text-side host logic
+
+def test_prompt_cleaning_matches_reference_rules():
+    """omnivideo/modules/tokenizers.py:12-36 of the reference: whitespace collapse, HTML unescape,
+    canonical form."""
+    from omnivideo.modules import tokenizers as K
+    assert K.whitespace_clean("  a \t\n  b   c ") == "a b c"
+    assert K.basic_clean(" &amp;lt;b&amp;gt; x ") == "<b> x"
+    assert K.canonicalize("Hello_World,  it's   ME!") == "hello world its me"
+    assert K.canonicalize("a.b|c.d", keep_punctuation_exact_string="|") == "ab|cd"
+
+
+def test_t5_bucket_table_equals_oracle():
+    from omnivideo.modules.t5 import T5RelativeEmbedding
+    from oracle import t5 as T
+    emb = T5RelativeEmbedding(32, 4, bidirectional=True)
+    for L in (1, 17, 300, 512):
+        assert torch.equal(emb.bucket_table(L, L).long(), T.relative_position_bucket(L, L, 32))
