@@ -160,6 +160,32 @@ int ovd_cfg_dpm_step(const float* cond, const float* uncond, const void* sample,
                      int sample_is_bf16, void* stream);
 #define OVD_DPM_COEF_STRIDE 8
 
+/* fp32 video -> uint8 frames [nvox, C] (T,H,W,C order): clamp to [lo, hi], (x - lo) / (hi - lo),
+ * times 255, truncate - the tensor half of cache_video (omnivideo/utils/utils.py:175-182, with
+ * torchvision.utils.make_grid's normalize for a single video).  Element x[v][c] is read at
+ * v*voxel_stride + c*channel_stride: (Cs, 1) for channels-last, (1, nvox) for planar [C,T,H,W]. */
+int ovd_video_to_uint8(const float* in, uint8_t* out, int64_t voxel_stride, int64_t channel_stride, int C,
+                       int64_t nvox, float lo, float hi, void* stream);
+
+/* Source-video frames -> VAE encoder input, the device half of transform_frames_to_tensor
+ * (tools/inference/generate_omni_v2v.py:306-343: CenterCrop, Resize on a PIL image = Pillow's 8-bit
+ * bilinear resample, ToTensor, Normalize).  frames [T,H,W,3] uint8; the crop window (top, left,
+ * crop_h, crop_w) is resized to out_h x out_w bit-exactly as Pillow does (horizontal pass into
+ * tmp [T,crop_h,out_w,3] uint8, then vertical), and each byte b is written as lut[b] (256 floats;
+ * the reference's map is (b/255 - 0.5)/0.5) to out [3,T,out_h,out_w] fp32 - the planar layout
+ * Wan2_1_VAE.encode takes.  The tap tables are DEVICE copies of what ovd_resize_coeffs fills. */
+int ovd_frames_resize_normalize(const uint8_t* frames, uint8_t* tmp, float* out, const int* bounds_w,
+                                const int* coef_w, int ksize_w, const int* bounds_h, const int* coef_h, int ksize_h,
+                                const float* lut, int64_t T, int H, int W, int top, int left, int crop_h, int crop_w,
+                                int out_h, int out_w, void* stream);
+
+/* HOST function (no GPU work): tap tables of one axis of that resize, in Pillow's arithmetic
+ * (third party: Pillow src/libImaging/Resample.c, precompute_coeffs + normalize_coeffs_8bpc,
+ * bilinear filter).  bounds_host [out_size][2] = (first tap, taps), coef_host [out_size][ksize_cap].
+ * Returns the tap-table width ksize (call with ksize_cap = 0 to learn it; nothing is written when
+ * ksize_cap < ksize), or -1 for sizes it does not serve (non-positive, or ksize > 64). */
+int ovd_resize_coeffs(int in_size, int out_size, int* bounds_host, int* coef_host, int ksize_cap);
+
 /* umT5 encoder self-attention (omnivideo/modules/t5.py:85-119): no score scaling, additive
  * relative-position bias, fp32 softmax, bf16 tensors between the steps:
  *   s = bf16(bf16(q.k) + pos_embedding[bucket[i][j]][head]);  keys j >= k_lens[b] get the lowest score

@@ -23,6 +23,10 @@ int ovd_impl_gemm_bf16(const bf16_t*, long, const bf16_t*, long, const bf16_t*, 
                        int, int, hipStream_t);
 int ovd_impl_attn_fwd(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, long, long,
                       long, long, long, long, long, long, float, int, hipStream_t);
+int ovd_impl_to_uint8(const float*, uint8_t*, long, long, int, long, float, float, hipStream_t);
+int ovd_impl_resize_coeffs(int, int, int*, int*, int);
+int ovd_impl_frames_resize(const uint8_t*, uint8_t*, float*, const int*, const int*, int, const int*, const int*, int,
+                           const float*, long, int, int, int, int, int, int, int, int, hipStream_t);
 int ovd_impl_t5_attention(const bf16_t*, long, const bf16_t*, const int*, const int*, bf16_t*, long, int, int, int, int,
                           hipStream_t);
 int ovd_impl_t5_gated_gelu(const bf16_t*, long, bf16_t*, long, int, int, hipStream_t);
@@ -160,6 +164,29 @@ int ovd_cfg_dpm_step(const float* cond, const float* uncond, const void* sample,
     OVD_REQUIRE(step_ptr != nullptr || step >= 0, "cfg_dpm: negative step");
     return ovd_impl_cfg_dpm_step(cond, uncond, sample, next, m1, coef, guide_scale, step_ptr, step, n,
                                  sample_is_bf16, ST(stream));
+}
+
+int ovd_video_to_uint8(const float* in, uint8_t* out, int64_t voxel_stride, int64_t channel_stride, int C,
+                       int64_t nvox, float lo, float hi, void* stream) {
+    NONNULL(in); NONNULL(out);
+    return ovd_impl_to_uint8(in, out, voxel_stride, channel_stride, C, nvox, lo, hi, ST(stream));
+}
+
+int ovd_resize_coeffs(int in_size, int out_size, int* bounds_host, int* coef_host, int ksize_cap) {
+    if (in_size <= 0 || out_size <= 0) return -1;
+    const int k = ovd_impl_resize_coeffs(in_size, out_size, nullptr, nullptr, 0);
+    if (k > 64) return -1;                          // more than 31x reduction: not a video preprocessing case
+    return ovd_impl_resize_coeffs(in_size, out_size, bounds_host, coef_host, ksize_cap);
+}
+
+int ovd_frames_resize_normalize(const uint8_t* frames, uint8_t* tmp, float* out, const int* bounds_w,
+                                const int* coef_w, int ksize_w, const int* bounds_h, const int* coef_h, int ksize_h,
+                                const float* lut, int64_t T, int H, int W, int top, int left, int crop_h, int crop_w,
+                                int out_h, int out_w, void* stream) {
+    NONNULL(frames); NONNULL(tmp); NONNULL(out); NONNULL(bounds_w); NONNULL(coef_w); NONNULL(bounds_h);
+    NONNULL(coef_h); NONNULL(lut);
+    return ovd_impl_frames_resize(frames, tmp, out, bounds_w, coef_w, ksize_w, bounds_h, coef_h, ksize_h, lut, T, H, W,
+                                  top, left, crop_h, crop_w, out_h, out_w, ST(stream));
 }
 
 int ovd_t5_attention_bf16(const uint16_t* qkv, int64_t ld, const uint16_t* pos_embedding, const int32_t* bucket,

@@ -29,6 +29,9 @@ SIGNATURES = {
     "ovd_head_unpatchify": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_cfg_unipc_step": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
     "ovd_cfg_dpm_step": [_p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
+    "ovd_video_to_uint8": [_p, _p, _l, _l, _i, _l, _f, _f, _p],
+    "ovd_resize_coeffs": [_i, _i, _p, _p, _i],
+    "ovd_frames_resize_normalize": [_p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_t5_attention_bf16": [_p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p],
     "ovd_t5_gated_gelu_bf16": [_p, _l, _p, _l, _i, _i, _p],
     "ovd_add_bf16": [_p, _p, _l, _p],
@@ -364,6 +367,55 @@ def vae_from_channels_last(x, channels=None, pre=None, mul=None, post=None, clam
     out = torch.empty(C, T, H, W, dtype=F32, device=x.device)
     _call("ovd_vae_from_channels_last", _f32c(x), _f32c(out), _f32c(pre, True), _f32c(mul, True), _f32c(post, True),
           C, Cs, T * H * W, int(clamp), _stream())
+    return out
+
+
+def video_to_uint8(x, channels_last, value_range=(-1.0, 1.0), channels=3):
+    """fp32 video -> uint8 [T,H,W,C]; x is channels-last [T,H,W,Cs] or planar [C,T,H,W]."""
+    if channels_last:
+        T, Hh, W, Cs = x.shape
+        vs, cs = Cs, 1
+    else:
+        C_, T, Hh, W = x.shape
+        if C_ != channels:
+            raise ValueError("video_to_uint8: planar input must have exactly `channels` channels")
+        vs, cs = 1, T * Hh * W
+    out = torch.empty(T, Hh, W, channels, dtype=torch.uint8, device=x.device)
+    _call("ovd_video_to_uint8", _f32c(x), out.data_ptr(), vs, cs, channels, T * Hh * W, float(value_range[0]),
+          float(value_range[1]), _stream())
+    return out
+
+
+def resize_coeffs(in_size, out_size, device):
+    """Device tap tables (bounds int32 [out, 2], coef int32 [out, ksize]) of one resize axis."""
+    L = lib()
+    ksize = L.ovd_resize_coeffs(in_size, out_size, None, None, 0)
+    if ksize <= 0:
+        raise ValueError(f"resize {in_size} -> {out_size} is not served (empty, or more than 31x reduction)")
+    bounds = torch.empty(out_size, 2, dtype=torch.int32)
+    coef = torch.empty(out_size, ksize, dtype=torch.int32)
+    if L.ovd_resize_coeffs(in_size, out_size, bounds.data_ptr(), coef.data_ptr(), ksize) != ksize:
+        raise RuntimeError("ovd_resize_coeffs: inconsistent tap-table width")
+    return bounds.to(device), coef.to(device), ksize
+
+
+def frames_resize_normalize(frames, crop, out_hw, lut):
+    """frames uint8 [T,H,W,3] on the device -> fp32 [3,T,out_h,out_w]; crop = (top, left, h, w)."""
+    if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous() or frames.dim() != 4 \
+            or frames.shape[3] != 3:
+        raise ValueError("frames must be a contiguous uint8 [T,H,W,3] tensor on the HIP device")
+    T, Hh, W, _ = frames.shape
+    top, left, ch, cw = crop
+    oh, ow = out_hw
+    if lut.numel() != 256:
+        raise ValueError("lut must hold 256 floats")
+    bw, kw, ksw = resize_coeffs(cw, ow, frames.device)
+    bh, kh, ksh = resize_coeffs(ch, oh, frames.device)
+    tmp = torch.empty(T, ch, ow, 3, dtype=torch.uint8, device=frames.device)
+    out = torch.empty(3, T, oh, ow, dtype=F32, device=frames.device)
+    _call("ovd_frames_resize_normalize", frames.data_ptr(), tmp.data_ptr(), out.data_ptr(), bw.data_ptr(),
+          kw.data_ptr(), ksw, bh.data_ptr(), kh.data_ptr(), ksh, _f32c(lut), T, Hh, W, top, left, ch, cw, oh, ow,
+          _stream())
     return out
 
 

@@ -348,8 +348,11 @@ class WanVAE_(nn.Module):
         run.reset()
         return z[None]
 
-    def decode(self, z, scale):
-        """z [1,z,T,h,w] -> video [1,3,4T-3,8h,8w] (reference vae2_1.py:543-567)."""
+    def decode(self, z, scale, as_frames=False):
+        """z [1,z,T,h,w] -> video [1,3,4T-3,8h,8w] (reference vae2_1.py:543-567).  With
+        `as_frames` the decoder's channels-last output is converted straight to the uint8
+        [4T-3,8h,8w,3] frames that the reference's cache_video hands to its video writer
+        (utils/utils.py:175-182), without materialising the planar fp32 video."""
         dev = self.conv1.weight.device
         if z.shape[0] != 1:
             raise NotImplementedError("batch of one, as the pipeline calls it")
@@ -361,6 +364,8 @@ class WanVAE_(nn.Module):
         outs = [run.decoder_chunk(x[i:i + 1]) for i in range(x.shape[0])]
         out = torch.cat(outs, dim=0)
         run.reset()
+        if as_frames:
+            return H.video_to_uint8(out, channels_last=True)
         return H.vae_from_channels_last(out)[None]
 
 
@@ -399,3 +404,8 @@ class Wan2_1_VAE:
     def decode(self, zs):
         """zs: list of [z,T,h,w] -> list of fp32 [3,4T-3,8h,8w] clamped to [-1,1]."""
         return [self.model.decode(u.unsqueeze(0), self.scale).float().clamp_(-1, 1).squeeze(0) for u in zs]
+
+    def decode_frames(self, zs):
+        """zs: list of [z,T,h,w] -> list of uint8 [4T-3,8h,8w,3] frames: decode() followed by the
+        tensor half of cache_video (reference utils/utils.py:175-182) in one pass."""
+        return [self.model.decode(u.unsqueeze(0), self.scale, as_frames=True) for u in zs]

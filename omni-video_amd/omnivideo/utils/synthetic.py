@@ -239,3 +239,24 @@ def make_t5_ids(cfg, batch, length, lens, seed=0):
     ids = torch.from_numpy(_rng(seed, "t5.ids").integers(0, cfg["vocab_size"], size=(batch, length)))
     mask = (torch.arange(length)[None, :] < torch.tensor(lens)[:, None]).long()
     return ids * mask, mask
+
+
+# name -> (frames, height, width, target height, target width) of the frame-preprocessing cases
+FRAME_CASES = {
+    "down_wide": (2, 45, 80, 24, 40),
+    "down_tall_crop": (2, 70, 50, 24, 40),
+    "up": (1, 20, 30, 32, 48),
+    "odd_crop": (1, 37, 61, 16, 28),
+    "odd_crop2": (1, 39, 63, 16, 28),
+    "same": (1, 24, 40, 24, 40),
+    "big_reduce": (1, 200, 356, 24, 40),
+    "portrait": (1, 64, 36, 40, 24),
+}
+
+
+def make_frames(name, T, Hh, W, seed=0):
+    """uint8 frames [T, H, W, 3]: full-range noise with saturated patches (exercises the clip)."""
+    f = _rng(seed, "frames." + name).integers(0, 256, size=(T, Hh, W, 3)).astype("uint8")
+    f[:, : Hh // 4, : W // 4] = 255
+    f[:, -(Hh // 4):, -(W // 4):] = 0
+    return f

@@ -4,7 +4,7 @@ modules (loaded by oracle/ref_loader.py from /root/reference) on CPU in float32.
 Only outputs are stored: weights and inputs are regenerated from their names by
 omnivideo.utils.synthetic, so the fixtures stay small.  Run from the repo root:
 
-    python oracle/gen_golden.py [dit] [unipc] [dpm] [t5] [vae]
+    python oracle/gen_golden.py [dit] [unipc] [dpm] [t5] [vae] [frames]
 
 The reference tree exists only in the build container; the committed .npz files are
 what travels.
@@ -177,8 +177,24 @@ def gen_t5():
     print("t5_tiny.npz:", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def gen_frames():
+    """Pillow itself (the library torchvision's Resize calls on PIL images) on seeded frames:
+    crop with the oracle's box, Image.resize(BILINEAR); only the resized bytes are stored."""
+    from PIL import Image
+    from oracle import video as V
+    out = {}
+    for name, (T, Hh, W, th, tw) in syn.FRAME_CASES.items():
+        frames = syn.make_frames(name, T, Hh, W)
+        top, left, ch, cw = V.center_crop_box(Hh, W, (th, tw))
+        res = [np.asarray(Image.fromarray(f[top:top + ch, left:left + cw]).resize((tw, th), Image.BILINEAR))
+               for f in frames]
+        out[name] = np.stack(res)
+    np.savez_compressed(os.path.join(GOLD, "frames.npz"), **out)
+    print("frames.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dit", "unipc", "dpm", "t5", "vae"]
+    which = sys.argv[1:] or ["dit", "unipc", "dpm", "t5", "vae", "frames"]
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     if "dit" in which:
@@ -189,6 +205,8 @@ if __name__ == "__main__":
         gen_dpm()
     if "t5" in which:
         gen_t5()
+    if "frames" in which:
+        gen_frames()
     if "vae" in which:
         from oracle import gen_golden_vae
         gen_golden_vae.main()

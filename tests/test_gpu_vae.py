@@ -186,3 +186,77 @@ def test_decode_encode_round_trip_shapes(vae):
     x = v.decode([z.cuda()])[0]
     z2 = v.encode([x])[0]
     assert tuple(z2.shape) == tuple(z.shape) and torch.isfinite(z2).all()
+
+
+def test_video_to_uint8_matches_reference_formula():
+    """uint8 frames: clamp, (x - lo) / (hi - lo), * 255, truncate (reference utils/utils.py:177-184
+    with make_grid's normalize for one video), from planar and from channels-last input."""
+    import omnivideo._hip as H
+    from omnivideo.utils.utils import video_to_frames, cache_video
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(3, 5, 34, 50, device="cuda", generator=g) * 0.8
+    x[0, 0, 0, :6] = torch.tensor([-1.0, 1.0, 0.0, -5.0, 5.0, 1.0 - 2.0 ** -24], device="cuda")
+    for lo, hi in ((-1.0, 1.0), (0.0, 1.0), (-0.5, 2.0)):
+        t = x.clamp(lo, hi)
+        want = ((t - lo) / max(hi - lo, 1e-5) * 255).type(torch.uint8).permute(1, 2, 3, 0).contiguous()
+        got = video_to_frames(x[None], value_range=(lo, hi))
+        assert got.dtype == torch.uint8 and torch.equal(got, want)
+        xcl = torch.zeros(5, 34, 50, 4, device="cuda")
+        xcl[..., :3] = x.permute(1, 2, 3, 0)
+        assert torch.equal(H.video_to_uint8(xcl, channels_last=True, value_range=(lo, hi)), want)
+    seen = {}
+    name = cache_video(x[None], save_file="/tmp/unused.mp4", fps=16, writer=lambda p, f, fps: seen.update(p=p, f=f, fps=fps))
+    assert name == "/tmp/unused.mp4" and seen["fps"] == 16 and seen["f"].shape == (5, 34, 50, 3)
+    assert cache_video(x[None], retry=2, writer=lambda p, f, fps: 1 / 0) is None
+
+
+def test_decode_frames_equals_decode_then_convert(vae):
+    v, _, _ = vae
+    z = syn.randn("vae.z3", (16, 3, 4, 4), 5).cuda()
+    vid = v.decode([z])[0]
+    frames = v.decode_frames([z])[0]
+    want = ((vid.clamp(-1, 1) + 1.0) / 2.0 * 255).type(torch.uint8).permute(1, 2, 3, 0)
+    assert torch.equal(frames, want)
+
+
+@pytest.mark.parametrize("name", list(syn.FRAME_CASES))
+def test_transform_frames_to_tensor_bit_exact(golden_dir, name):
+    """crop + Pillow-exact resize + ToTensor/Normalize on the device vs Pillow's bytes (golden) mapped
+    through the reference's fp32 arithmetic, and vs the CPU restatement: bit for bit."""
+    from omnivideo.utils.utils import transform_frames_to_tensor
+    from oracle import video as OV
+    T, Hh, W, th, tw = syn.FRAME_CASES[name]
+    frames = syn.make_frames(name, T, Hh, W)
+    got = transform_frames_to_tensor(frames, (th, tw))
+    assert tuple(got.shape) == (T, 3, th, tw) and got.transpose(0, 1).is_contiguous()
+    gold = torch.from_numpy(np.load(os.path.join(golden_dir, "frames.npz"))[name].astype(np.int64))
+    want = OV.normalize_lut()[gold].permute(0, 3, 1, 2)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(got.cpu(), OV.transform_frames_to_tensor(frames, (th, tw)))
+
+
+def test_transform_frames_full_size_properties():
+    """720p source -> 480p target at 49 frames: constant frames stay constant, the result is within
+    [-1, 1], frames are independent, and sampled frames equal the CPU restatement."""
+    from omnivideo.utils.utils import transform_frames_to_tensor
+    from oracle import video as OV
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (49, 720, 1280, 3), generator=g, dtype=torch.uint8)
+    frames[7] = 93
+    out = transform_frames_to_tensor(frames, (480, 832))
+    assert tuple(out.shape) == (49, 3, 480, 832)
+    lut = OV.normalize_lut()
+    assert torch.equal(out[7].cpu(), torch.full((3, 480, 832), float(lut[93])))
+    assert float(out.min()) >= -1.0 and float(out.max()) <= 1.0
+    for i in (0, 48):
+        assert torch.equal(out[i].cpu(), OV.transform_frames_to_tensor(frames[i:i + 1].numpy(), (480, 832))[0])
+    assert torch.equal(transform_frames_to_tensor(frames[20:22], (480, 832)), out[20:22])
+
+
+def test_frames_resize_rejects_bad_input():
+    import omnivideo._hip as H
+    lut = torch.zeros(256, device="cuda")
+    with pytest.raises(ValueError):
+        H.frames_resize_normalize(torch.zeros(1, 8, 8, 3, device="cuda"), (0, 0, 8, 8), (4, 4), lut)
+    with pytest.raises(RuntimeError, match="crop window"):
+        H.frames_resize_normalize(torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device="cuda"), (2, 0, 8, 8), (4, 4), lut)

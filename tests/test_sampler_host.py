@@ -144,3 +144,21 @@ def test_t5_bucket_table_equals_oracle():
     emb = T5RelativeEmbedding(32, 4, bidirectional=True)
     for L in (1, 17, 300, 512):
         assert torch.equal(emb.bucket_table(L, L).long(), T.relative_position_bucket(L, L, 32))
+
+
+def test_best_output_size_properties():
+    """omnivideo/utils/utils.py:135-158: multiples of the strides, within the area, and the
+    exact size back when the request already fits."""
+    pytest.importorskip("torch")
+    import importlib.util, os, sys, types
+    # the helper is pure host arithmetic; load the module without the HIP library
+    root = os.path.join(os.path.dirname(__file__), "..", "omni-video_amd", "omnivideo", "utils", "utils.py")
+    src = open(root).read().replace("from .. import _hip as H", "H = None")
+    mod = types.ModuleType("ov_utils_host")
+    exec(compile(src, root, "exec"), mod.__dict__)
+    assert mod.best_output_size(832, 480, 16, 16, 832 * 480) == (832, 480)
+    assert mod.best_output_size(1280, 720, 16, 16, 1280 * 720) == (1280, 720)
+    for (w, h, dw, dh, area) in [(1920, 1080, 16, 16, 832 * 480), (333, 777, 32, 16, 500000), (1000, 1000, 8, 8, 704 * 704)]:
+        ow, oh = mod.best_output_size(w, h, dw, dh, area)
+        assert ow % dw == 0 and oh % dh == 0 and ow * oh <= area
+        assert abs(ow / oh - w / h) / (w / h) < 0.1
