@@ -5,7 +5,8 @@ from .attention import flash_attention
 from .model import WanModel
 from .t5 import T5Encoder, T5EncoderModel
 from .tokenizers import HuggingfaceTokenizer
+from .vae2_1 import Wan2_1_VAE
 from .visual_context_adapter import VisualContextAdapter
 
-__all__ = ["WanModel", "flash_attention", "VisualContextAdapter", "T5Encoder", "T5EncoderModel",
+__all__ = ["Wan2_1_VAE", "WanModel", "flash_attention", "VisualContextAdapter", "T5Encoder", "T5EncoderModel",
            "HuggingfaceTokenizer"]
