@@ -39,6 +39,9 @@ WORKLOADS = {
     "cfg4": dict(desc="OmniVideo2-A14B T2V 81f 1280x720 50 steps bf16 (one expert resident in the bench)", model="A14B",
                  latent=(16, 21, 90, 160), frames=81, steps=50, text_len=6144, n_text=20, n_vlm=60, n_null=126,
                  visual=False),
+    "cfg5": dict(desc="OmniVideo2-A14B V2V 81f 1280x720 40 steps, e4m3 linear layers + bf16 attention "
+                      "(one expert resident in the bench)", model="A14B", latent=(16, 21, 90, 160), frames=81, steps=40,
+                 text_len=6144, n_text=550, n_vlm=700, n_null=126, visual=True, precision="fp8"),
     "cfg1": dict(desc="OmniVideo2-1.3B T2V 17f 256x256 20 steps (bf16 on GPU)", model="1.3B", latent=(16, 5, 32, 32),
                  frames=17, steps=20, text_len=512, n_text=20, n_vlm=60, n_null=126, visual=False),
 }
@@ -110,6 +113,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
+    ap.add_argument("--precision", choices=["bf16", "fp8"], default=None,
+                    help="arithmetic of the large linear layers (default: the workload's; fp8 only for cfg5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE decode leg")
@@ -146,6 +151,8 @@ def main():
         raise SystemExit(f"1 setup + {W} warmup + {K} timed steps exceed the workload's {wl['steps']} sampling steps")
     BF16 = torch.bfloat16
     model = build_model(cfg, wl["text_len"], dev)
+    precision = args.precision or wl.get("precision", "bf16")
+    model.wan_model.linear_precision = precision
     g = torch.Generator(device=dev).manual_seed(1818 + 1000 * rank)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g)
     special = {k: rn(1, cfg["text_dim"]).to(BF16) for k in ("<img_st>", "<img_ed>", "<prp_st>", "<prp_ed>")}
@@ -239,8 +246,10 @@ def main():
         out = {
             "metric": "denoised frames/sec (whole node)", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": wl["desc"], "latent": list(wl["latent"]), "tokens": seq_len,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if precision == "bf16" else "fp8 (e4m3 linear layers, bf16 attention, fp32 residual stream)",
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "linear_precision": precision, "latent": list(wl["latent"]), "tokens": seq_len,
                        "context_len": wl["text_len"], "context_keys_read": cache.k_len, "sampling_steps": wl["steps"], "guide_scale": 3.0,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "scope": "sampling loop (2 DiT forwards + CFG + UniPC per step); per-video context "

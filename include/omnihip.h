@@ -167,6 +167,31 @@ int ovd_cfg_dpm_step(const float* cond, const float* uncond, const void* sample,
 int ovd_video_to_uint8(const float* in, uint8_t* out, int64_t voxel_stride, int64_t channel_stride, int C,
                        int64_t nvox, float lo, float hi, void* stream);
 
+/* ---- FP8 (OCP e4m3) mode of the linear layers.  The reference has no FP8 path: it runs these
+ * layers in bf16 (omnivideo/modules/model.py:125-154 self-attention projections, :159-179 cross-
+ * attention projections, :218-258 feed-forward); this mode is the reduced-precision configuration
+ * for the largest model and is checked against this library's own bf16 entries. ---- */
+
+/* bf16 rows [M, K] -> e4m3 rows q [M, K] and scale[m] = absmax(row m) / 448 (1 for an all-zero row),
+ * so that x[m][k] ~ q[m][k] * scale[m].  K % 8 == 0, K <= 14336.  Weights [N, K] of nn.Linear get
+ * one scale per output channel this way (once per model); activations one scale per token row. */
+int ovd_quant_rows_fp8(const void* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int M, int K, void* stream);
+
+/* ovd_layernorm_modulate_bf16 followed by ovd_quant_rows_fp8 of its bf16 result, in one pass. */
+int ovd_layernorm_modulate_fp8(const float* x, int64_t ldx, const float* shift, const float* scale, const void* weight,
+                               const void* bias, uint8_t* out, int64_t ldo, float* row_scale, int M, int C, float eps,
+                               int round_norm, void* stream);
+
+/* out = epilogue( (sum_k A[m][k] * W[n][k]) * a_scale[m] * a_scale_all * w_scale[n] + bias[n] ) on e4m3
+ * operands with fp32 accumulation (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales).  a_scale may
+ * be NULL (1 per row).  Epilogues 0-3 as ovd_gemm_bf16; 4 (OVD_EPI_FP8_GELU): out is e4m3 [M, N] holding
+ * bf16(gelu(bf16(.))) / out_scale, saturated at +-448, for a following ovd_gemm_fp8 with
+ * a_scale_all = out_scale.  N % 256 == 0, K % 64 == 0, K >= 128, lda/ldw % 16 == 0, each operand < 4 GiB. */
+#define OVD_EPI_FP8_GELU 4
+int ovd_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, float a_scale_all, const uint8_t* W, int64_t ldw,
+                 const float* w_scale, const void* bias, void* out, int64_t ldo, const float* gate, float out_scale,
+                 int M, int N, int K, int epilogue, void* stream);
+
 /* Source-video frames -> VAE encoder input, the device half of transform_frames_to_tensor
  * (tools/inference/generate_omni_v2v.py:306-343: CenterCrop, Resize on a PIL image = Pillow's 8-bit
  * bilinear resample, ToTensor, Normalize).  frames [T,H,W,3] uint8; the crop window (top, left,

@@ -25,6 +25,11 @@ int ovd_impl_attn_fwd(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int,
                       long, long, long, long, long, long, float, int, hipStream_t);
 int ovd_impl_to_uint8(const float*, uint8_t*, long, long, int, long, float, float, hipStream_t);
 int ovd_impl_resize_coeffs(int, int, int*, int*, int);
+int ovd_impl_quant_rows_fp8(const bf16_t*, long, uint8_t*, long, float*, int, int, hipStream_t);
+int ovd_impl_ln_fp8(const float*, long, const float*, const float*, const bf16_t*, const bf16_t*, uint8_t*, long, float*,
+                    int, int, float, int, hipStream_t);
+int ovd_impl_gemm_fp8(const uint8_t*, long, const float*, float, const uint8_t*, long, const float*, const bf16_t*, void*,
+                      long, const float*, float, int, int, int, int, hipStream_t);
 int ovd_impl_frames_resize(const uint8_t*, uint8_t*, float*, const int*, const int*, int, const int*, const int*, int,
                            const float*, long, int, int, int, int, int, int, int, int, hipStream_t);
 int ovd_impl_t5_attention(const bf16_t*, long, const bf16_t*, const int*, const int*, bf16_t*, long, int, int, int, int,
@@ -170,6 +175,27 @@ int ovd_video_to_uint8(const float* in, uint8_t* out, int64_t voxel_stride, int6
                        int64_t nvox, float lo, float hi, void* stream) {
     NONNULL(in); NONNULL(out);
     return ovd_impl_to_uint8(in, out, voxel_stride, channel_stride, C, nvox, lo, hi, ST(stream));
+}
+
+int ovd_quant_rows_fp8(const void* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int M, int K, void* stream) {
+    NONNULL(x); NONNULL(q); NONNULL(scale);
+    return ovd_impl_quant_rows_fp8((const bf16_t*)x, ldx, q, ldq, scale, M, K, ST(stream));
+}
+
+int ovd_layernorm_modulate_fp8(const float* x, int64_t ldx, const float* shift, const float* scale, const void* weight,
+                               const void* bias, uint8_t* out, int64_t ldo, float* row_scale, int M, int C, float eps,
+                               int round_norm, void* stream) {
+    NONNULL(x); NONNULL(out); NONNULL(row_scale);
+    return ovd_impl_ln_fp8(x, ldx, shift, scale, (const bf16_t*)weight, (const bf16_t*)bias, out, ldo, row_scale, M, C,
+                           eps, round_norm, ST(stream));
+}
+
+int ovd_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, float a_scale_all, const uint8_t* W, int64_t ldw,
+                 const float* w_scale, const void* bias, void* out, int64_t ldo, const float* gate, float out_scale,
+                 int M, int N, int K, int epilogue, void* stream) {
+    NONNULL(A); NONNULL(W); NONNULL(w_scale); NONNULL(out);
+    return ovd_impl_gemm_fp8(A, lda, a_scale, a_scale_all, W, ldw, w_scale, (const bf16_t*)bias, out, ldo, gate,
+                             out_scale, M, N, K, epilogue, ST(stream));
 }
 
 int ovd_resize_coeffs(int in_size, int out_size, int* bounds_host, int* coef_host, int ksize_cap) {

@@ -1,0 +1,410 @@
+// FP8 (OCP e4m3) path of the linear layers: the reduced-precision mode for the largest model
+// (no counterpart in the reference, which runs these layers in bf16: omnivideo/modules/model.py
+// :125-154, :159-179, :218-258 are the layers it serves; results are compared with this build's
+// own bf16 path).
+//
+//   quant_rows_fp8_kernel   bf16 rows -> e4m3 rows + one fp32 scale per row (absmax / 448);
+//                           used once for weights ([N, K]: a scale per output channel) and per
+//                           call for activations that a bf16 kernel produced
+//   ln_mod_fp8_kernel       the LayerNorm + modulation kernel of norm.hip with that same row
+//                           quantisation fused into its write pass
+//   gemm_fp8_kernel<EPI>    out = epilogue((sum_k A8[m][k] W8[n][k]) * sa[m] * sw[n] + bias[n])
+//
+// The GEMM is the 256 x 256 ring-pipelined kernel of gemm256.hip with the K-tile kept at 64
+// BYTES per row: the DMA, the LDS image and its swizzle, the counted waits and the half-phase
+// stagger of the two wave groups are byte-identical; a K-tile now holds 64 k-values and is
+// consumed by 8 v_mfma_scale_f32_32x32x64_f8f6f4 per wave (unit block scales), which take the
+// time of the 32 bf16 MFMAs they replace for twice the K.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+constexpr float FP8_MAX = 448.f;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// four floats -> four e4m3 bytes (round to nearest even, saturating at +-448)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -FP8_MAX), FP8_MAX);
+    b = fminf(fmaxf(b, -FP8_MAX), FP8_MAX);
+    c = fminf(fmaxf(c, -FP8_MAX), FP8_MAX);
+    d = fminf(fmaxf(d, -FP8_MAX), FP8_MAX);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+
+// ------------------------------------------------------------------------- row quantisation
+// one wave per row; the row (K <= 512 * VPL values, K % 8 == 0) stays in registers between the two passes
+template <int VPL>
+__global__ void __launch_bounds__(256) quant_rows_fp8_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                             uint8_t* __restrict__ q, long ldq,
+                                                             float* __restrict__ scale, int M, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (long)row * ldx);
+    uint4 v[VPL];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = (i * 64 + lane) * 8 < K ? xr[i * 64 + lane] : make_uint4(0, 0, 0, 0);
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            mx = fmaxf(mx, fmaxf(fabsf(bf2f(w[j] & 0xffff)), fabsf(bf2f(w[j] >> 16))));
+    }
+    mx = wave_max(mx);
+    const float s = mx > 0.f ? mx / FP8_MAX : 1.f;
+    const float inv = 1.f / s;
+    if (lane == 0) scale[row] = s;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        uint2 o;
+        o.x = pack_fp8x4(bf2f(w[0] & 0xffff) * inv, bf2f(w[0] >> 16) * inv, bf2f(w[1] & 0xffff) * inv,
+                         bf2f(w[1] >> 16) * inv);
+        o.y = pack_fp8x4(bf2f(w[2] & 0xffff) * inv, bf2f(w[2] >> 16) * inv, bf2f(w[3] & 0xffff) * inv,
+                         bf2f(w[3] >> 16) * inv);
+        if ((i * 64 + lane) * 8 < K) *reinterpret_cast<uint2*>(q + (long)row * ldq + (i * 64 + lane) * 8) = o;
+    }
+}
+
+// LayerNorm (+ affine) (+ modulation) as ln_mod_kernel of norm.hip computes it, rounded to bf16 as
+// that kernel's output is, then quantised per row.
+template <int VPL>
+__global__ void __launch_bounds__(256) ln_mod_fp8_kernel(const float* __restrict__ x, long ldx,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ scale,
+                                                         const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                         uint8_t* __restrict__ out, long ldo,
+                                                         float* __restrict__ row_scale, int M, int C, float eps,
+                                                         int round_norm) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = xr[i * 64 + lane];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        qq += (a * a + bb * bb) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(qq) / (float)C + eps);
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd,
+                      (v[i].w - mean) * rstd};
+        if (w) {
+            const uint2 wp = *reinterpret_cast<const uint2*>(w + col);
+            const uint2 bp = *reinterpret_cast<const uint2*>(b + col);
+            y[0] = y[0] * bf2f(wp.x & 0xffff) + bf2f(bp.x & 0xffff);
+            y[1] = y[1] * bf2f(wp.x >> 16) + bf2f(bp.x >> 16);
+            y[2] = y[2] * bf2f(wp.y & 0xffff) + bf2f(bp.y & 0xffff);
+            y[3] = y[3] * bf2f(wp.y >> 16) + bf2f(bp.y >> 16);
+        }
+        if (round_norm) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = round_bf(y[j]);
+        }
+        if (scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + col);
+            const float4 sh = *reinterpret_cast<const float4*>(shift + col);
+            y[0] = y[0] * (1.f + sc.x) + sh.x;
+            y[1] = y[1] * (1.f + sc.y) + sh.y;
+            y[2] = y[2] * (1.f + sc.z) + sh.z;
+            y[3] = y[3] * (1.f + sc.w) + sh.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = round_bf(y[j]);
+            mx = fmaxf(mx, fabsf(y[j]));
+        }
+        v[i] = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    mx = wave_max(mx);
+    const float sq = mx > 0.f ? mx / FP8_MAX : 1.f;
+    const float inv = 1.f / sq;
+    if (lane == 0) row_scale[row] = sq;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+        *reinterpret_cast<uint32_t*>(out + (long)row * ldo + (i * 64 + lane) * 4) =
+            pack_fp8x4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+}
+
+// ------------------------------------------------------------------------------------- GEMM
+constexpr int TM = 256, TN = 256, TKB = 64, NSTAGE = 4;   // TKB: bytes (= fp8 k-values) per K-tile row
+constexpr int PART = 256 * TKB;        // 16 KiB: one operand of one K-tile
+constexpr int STAGE = 2 * PART;        // A part | W part
+
+enum Epi { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_FP8_GELU = 4 };
+
+struct Src {
+    const char* base;
+    unsigned off[2];
+};
+
+__device__ __forceinline__ void stage_part(const Src& s, long kbyte, char* dst_wave) {
+    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[0], (lds_ptr)dst_wave, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[1], (lds_ptr)(dst_wave + 8 * 1024), 16, 0, 0);
+}
+
+// fragment of a 32-row block: lane (r = lane & 31, h = lane >> 5) takes bytes 32h .. 32h + 31 of row r
+__device__ __forceinline__ i32x8 lds_frag8(const char* blk, int off0, int off1) {
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(blk + off0);
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(blk + off1);
+    return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <bool STAGE_NEXT, int VMCNT>
+__device__ __forceinline__ void k_tile8(f32x16 (&acc)[2][4], const char* smem, int kt, const Src& sa, const Src& sw,
+                                        int off0, int off1, int a_rd, int w_rd, int wave) {
+    const char* st = smem + (kt & (NSTAGE - 1)) * STAGE;
+    char* nx = const_cast<char*>(smem) + ((kt + 2) & (NSTAGE - 1)) * STAGE + wave * 1024;
+    const long kb = (long)(kt + 2) * TKB;
+    i32x8 wf[2], af[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wf[t] = lds_frag8(st + PART + w_rd + t * 2048, off0, off1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) af[t] = lds_frag8(st + a_rd + t * 2048, off0, off1);
+    if (STAGE_NEXT) {
+        stage_part(sw, kb, nx + PART);
+        stage_part(sa, kb, nx);
+    }
+    if (VMCNT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (VMCNT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[nt], af[mt], acc[nt][mt], 0, 0, 0,
+                                                                          0x7F7F7F7F, 0, 0x7F7F7F7F);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict__ a_scale, float a_scale_all,
+                const uint8_t* __restrict__ W, long ldw, const float* __restrict__ w_scale,
+                const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
+                float out_inv_scale, int M, int N, int K, int tiles_m, int tiles_n, int GM) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group;
+    const int first_m = grp * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + (bid % per_group) % gsz;
+    const int tn = (bid % per_group) / gsz;
+    const int row0 = tm * TM, col0 = tn * TN;
+
+    Src sa, sw;
+    sa.base = reinterpret_cast<const char*>(A);
+    sw.base = reinterpret_cast<const char*>(W);
+    {
+        const int c = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (i * 8 + wave) * 16 + (lane >> 2);
+            const int ar = min(row0 + r, M - 1);
+            sa.off[i] = (unsigned)ar * (unsigned)lda + (unsigned)c * 16u;
+            sw.off[i] = (unsigned)(col0 + r) * (unsigned)ldw + (unsigned)c * 16u;
+        }
+    }
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sz = (4 - ((fr >> 2) & 3)) & 3;
+    const int off0 = fr * 64 + (((2 * fh) ^ sz) << 4), off1 = fr * 64 + (((2 * fh + 1) ^ sz) << 4);
+    const int a_rd = wr * 8192, w_rd = wc * 4096;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = K / TKB;      // >= 2 (checked on the host)
+    char* const wdst = smem + wave * 1024;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        stage_part(sw, (long)t * TKB, wdst + t * STAGE + PART);
+        stage_part(sa, (long)t * TKB, wdst + t * STAGE);
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: half a phase behind
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) k_tile8<true, 4>(acc, smem, kt, sa, sw, off0, off1, a_rd, w_rd, wave);
+    k_tile8<false, 0>(acc, smem, kt, sa, sw, off0, off1, a_rd, w_rd, wave);
+    k_tile8<false, -1>(acc, smem, kt + 1, sa, sw, off0, off1, a_rd, w_rd, wave);
+    if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
+
+    // epilogue: acc[nt][mt] register 4g + j is out[m][n + j], m = row0 + wr*128 + mt*32 + (lane & 31),
+    // n = col0 + wc*64 + nt*32 + 8g + 4*(lane >> 5)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = row0 + wr * 128 + mt * 32 + fr;
+        if (m >= M) continue;
+        const float sa_m = (a_scale ? a_scale[m] : 1.f) * a_scale_all;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = col0 + wc * 64 + nt * 32 + 8 * g + 4 * fh;
+                const float4 ws = *reinterpret_cast<const float4*>(w_scale + n);
+                float y[4] = {acc[nt][mt][4 * g] * (sa_m * ws.x), acc[nt][mt][4 * g + 1] * (sa_m * ws.y),
+                              acc[nt][mt][4 * g + 2] * (sa_m * ws.z), acc[nt][mt][4 * g + 3] * (sa_m * ws.w)};
+                if (bias) {
+                    const uint2 bp = *reinterpret_cast<const uint2*>(bias + n);
+                    y[0] += bf2f(bp.x & 0xffff);
+                    y[1] += bf2f(bp.x >> 16);
+                    y[2] += bf2f(bp.y & 0xffff);
+                    y[3] += bf2f(bp.y >> 16);
+                }
+                if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+                    if (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(round_bf(y[j]));
+                    }
+                    uint2 o;
+                    o.x = pack_bf2(y[0], y[1]);
+                    o.y = pack_bf2(y[2], y[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)m * ldo + n) = o;
+                } else if (EPI == EPI_FP8_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = round_bf(gelu_tanh_f(round_bf(y[j]))) * out_inv_scale;
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + (long)m * ldo + n) =
+                        pack_fp8x4(y[0], y[1], y[2], y[3]);
+                } else if (EPI == EPI_F32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)m * ldo + n) =
+                        make_float4(round_bf(y[0]), round_bf(y[1]), round_bf(y[2]), round_bf(y[3]));
+                } else {
+                    float gv[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (gate) {
+                        const float4 g4 = *reinterpret_cast<const float4*>(gate + n);
+                        gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+                    }
+                    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)m * ldo + n);
+                    float4 x = *p;
+                    x.x += round_bf(y[0]) * gv[0];
+                    x.y += round_bf(y[1]) * gv[1];
+                    x.z += round_bf(y[2]) * gv[2];
+                    x.w += round_bf(y[3]) * gv[3];
+                    *p = x;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+int ovd_impl_quant_rows_fp8(const bf16_t* x, long ldx, uint8_t* q, long ldq, float* scale, int M, int K,
+                            hipStream_t st) {
+    OVD_REQUIRE(K % 8 == 0 && K > 0 && K <= 512 * 28, "quant_rows_fp8: K=%d must be a multiple of 8, at most 14336", K);
+    OVD_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K, "quant_rows_fp8: bad row strides");
+    if (M == 0) return 0;
+    dim3 grid(ceil_div(M, 4)), blk(256);
+    const int vpl = ceil_div(K, 512);
+#define Q_CASE(V) \
+    if (vpl <= V) { hipLaunchKernelGGL((quant_rows_fp8_kernel<V>), grid, blk, 0, st, x, ldx, q, ldq, scale, M, K); } else
+    Q_CASE(1) Q_CASE(3) Q_CASE(6) Q_CASE(10) Q_CASE(18) Q_CASE(28) {}
+#undef Q_CASE
+    OVD_CHECK_LAUNCH("quant_rows_fp8");
+    return 0;
+}
+
+int ovd_impl_ln_fp8(const float* x, long ldx, const float* shift, const float* scale, const bf16_t* w,
+                    const bf16_t* b, uint8_t* out, long ldo, float* row_scale, int M, int C, float eps,
+                    int round_norm, hipStream_t st) {
+    OVD_REQUIRE(C % 256 == 0, "layernorm fp8: C=%d must be a multiple of 256", C);
+    OVD_REQUIRE((w == nullptr) == (b == nullptr), "layernorm fp8: weight and bias must come together");
+    OVD_REQUIRE((scale == nullptr) == (shift == nullptr), "layernorm fp8: scale and shift must come together");
+    OVD_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "layernorm fp8: row strides must be multiples of 4");
+    if (M == 0) return 0;
+    dim3 grid(ceil_div(M, 4)), blk(256);
+#define LN_CASE(V)                                                                                          \
+    case V:                                                                                                 \
+        hipLaunchKernelGGL((ln_mod_fp8_kernel<V>), grid, blk, 0, st, x, ldx, shift, scale, w, b, out, ldo,     \
+                           row_scale, M, C, eps, round_norm);                                               \
+        break;
+    switch (C / 256) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(6) LN_CASE(8) LN_CASE(12) LN_CASE(16) LN_CASE(20)
+        default:
+            OVD_FAIL("layernorm fp8: unsupported width C=%d", C);
+    }
+#undef LN_CASE
+    OVD_CHECK_LAUNCH("layernorm fp8");
+    return 0;
+}
+
+bool ovd_gemm_fp8_applicable(long lda, long ldw, int M, int N, int K) {
+    return M > 0 && N % TN == 0 && K % TKB == 0 && K >= 2 * TKB && lda % 16 == 0 && ldw % 16 == 0 &&
+           (long)M * lda < (1L << 32) && (long)N * ldw < (1L << 32);
+}
+
+int ovd_impl_gemm_fp8(const uint8_t* A, long lda, const float* a_scale, float a_scale_all, const uint8_t* W, long ldw,
+                      const float* w_scale, const bf16_t* bias, void* out, long ldo, const float* gate,
+                      float out_scale, int M, int N, int K, int epilogue, hipStream_t st) {
+    OVD_REQUIRE(ovd_gemm_fp8_applicable(lda, ldw, M, N, K),
+                "gemm_fp8: shape M=%d N=%d K=%d (lda %ld, ldw %ld) not supported: N %% 256, K %% 64, K >= 128, "
+                "strides %% 16, operands < 4 GiB", M, N, K, lda, ldw);
+    OVD_REQUIRE(lda >= K && ldw >= K && ldo >= N && ldo % 4 == 0, "gemm_fp8: bad strides");
+    OVD_REQUIRE(out_scale > 0.f && a_scale_all > 0.f, "gemm_fp8: scales must be positive");
+    const int tiles_m = ceil_div(M, TM), tiles_n = N / TN;
+    dim3 grid(tiles_m * tiles_n), blk(512);
+    const size_t lds = NSTAGE * STAGE;
+    const float out_inv = 1.f / out_scale;
+#define GEMM_CASE(E)                                                                                      \
+    case E: {                                                                                             \
+        static bool attr_set = false;                                                                     \
+        if (!attr_set) {                                                                                  \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fp8_kernel<E>),                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+                OVD_FAIL("gemm_fp8: cannot reserve %zu bytes of LDS", lds);                                \
+            attr_set = true;                                                                              \
+        }                                                                                                 \
+        hipLaunchKernelGGL((gemm_fp8_kernel<E>), grid, blk, lds, st, A, lda, a_scale, a_scale_all, W, ldw, \
+                           w_scale, bias, out, ldo, gate, out_inv, M, N, K, tiles_m, tiles_n, 4);         \
+    } break;
+    switch (epilogue) {
+        GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) GEMM_CASE(EPI_FP8_GELU)
+        default:
+            OVD_FAIL("gemm_fp8: unknown epilogue %d", epilogue);
+    }
+#undef GEMM_CASE
+    OVD_CHECK_LAUNCH("gemm_fp8");
+    return 0;
+}

@@ -30,6 +30,9 @@ SIGNATURES = {
     "ovd_cfg_unipc_step": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
     "ovd_cfg_dpm_step": [_p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
     "ovd_video_to_uint8": [_p, _p, _l, _l, _i, _l, _f, _f, _p],
+    "ovd_quant_rows_fp8": [_p, _l, _p, _l, _p, _i, _i, _p],
+    "ovd_layernorm_modulate_fp8": [_p, _l, _p, _p, _p, _p, _p, _l, _p, _i, _i, _f, _i, _p],
+    "ovd_gemm_fp8": [_p, _l, _p, _f, _p, _l, _p, _p, _p, _l, _p, _f, _i, _i, _i, _i, _p],
     "ovd_resize_coeffs": [_i, _i, _p, _p, _i],
     "ovd_frames_resize_normalize": [_p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_t5_attention_bf16": [_p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p],
@@ -383,6 +386,50 @@ def video_to_uint8(x, channels_last, value_range=(-1.0, 1.0), channels=3):
     out = torch.empty(T, Hh, W, channels, dtype=torch.uint8, device=x.device)
     _call("ovd_video_to_uint8", _f32c(x), out.data_ptr(), vs, cs, channels, T * Hh * W, float(value_range[0]),
           float(value_range[1]), _stream())
+    return out
+
+
+EPI_FP8_GELU = 4
+
+
+def _u8(t):
+    if t.dtype != torch.uint8 or not t.is_cuda or t.stride(-1) != 1:
+        raise ValueError("expected a uint8 (e4m3 bit pattern) tensor on the HIP device")
+    return t.data_ptr()
+
+
+def quant_rows_fp8(x, q=None, scale=None):
+    """bf16 [M, K] -> (e4m3 bytes [M, K] uint8, fp32 scale [M]): x ~ q * scale[:, None]."""
+    M, K = x.shape
+    if q is None:
+        q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty(M, dtype=F32, device=x.device)
+    _call("ovd_quant_rows_fp8", _ptr(x, BF16), x.stride(0), _u8(q), q.stride(0), _f32c(scale), M, K, _stream())
+    return q, scale
+
+
+def layernorm_modulate_fp8(x, out, row_scale, eps, shift=None, scale=None, weight=None, bias=None, round_norm=False):
+    M, C = x.shape
+    _call("ovd_layernorm_modulate_fp8", _f32c(x), x.stride(0), _f32c(shift, True), _f32c(scale, True),
+          _ptr(weight, BF16, True), _ptr(bias, BF16, True), _u8(out), out.stride(0), _f32c(row_scale), M, C,
+          float(eps), int(round_norm), _stream())
+    return out
+
+
+def gemm_fp8(a8, w8, w_scale, out, bias=None, epilogue=EPI_BF16, a_scale=None, a_scale_all=1.0, gate=None,
+             out_scale=1.0):
+    """out = epilogue((a8 @ w8.T) * a_scale[:, None] * a_scale_all * w_scale[None, :] + bias)."""
+    M, K = a8.shape
+    N = w8.shape[0]
+    if w8.shape[1] != K or out.shape[0] != M or out.shape[1] != N:
+        raise ValueError("gemm_fp8: shape mismatch")
+    want = {EPI_BF16: BF16, EPI_BF16_GELU: BF16, EPI_F32: F32, EPI_RESID: F32, EPI_FP8_GELU: torch.uint8}[epilogue]
+    if out.dtype != want or out.stride(1) != 1:
+        raise ValueError("gemm_fp8: output dtype/stride does not match the epilogue")
+    _call("ovd_gemm_fp8", _u8(a8), a8.stride(0), _f32c(a_scale, True), float(a_scale_all), _u8(w8), w8.stride(0),
+          _f32c(w_scale), _ptr(bias, BF16, True), out.data_ptr(), out.stride(0), _f32c(gate, True), float(out_scale),
+          M, N, K, epilogue, _stream())
     return out
 
 

@@ -89,9 +89,20 @@ class TorchGroupComm:
         dist.all_reduce(t, group=self.group)
 
 
+FP8_LINEARS = ("qkv", "o", "cq", "co", "f0", "f2")
+
+
 class DiTEngine:
-    def __init__(self, model, device=None):
-        """model: omnivideo.modules.model.WanModel (parameters are read, never modified)."""
+    def __init__(self, model, device=None, precision="bf16"):
+        """model: omnivideo.modules.model.WanModel (parameters are read, never modified).
+        precision: "bf16" (the reference's arithmetic) or "fp8": the six large linear layers of
+        every block run on e4m3 operands - weights quantised once with a scale per output
+        channel, activations per token row inside the kernel that produces them (the GELU output
+        with the fixed scale `ffn_act_scale`); everything else is unchanged."""
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
+        self.precision = precision
+        self.ffn_act_scale = 1.0
         p0 = model.patch_embedding.weight
         self.device = torch.device(device) if device is not None else p0.device
         if self.device.type != "cuda":
@@ -129,6 +140,10 @@ class DiTEngine:
                 w_co=w(ca.o.weight), b_co=w(ca.o.bias),
                 w_f0=w(blk.ffn[0].weight), b_f0=w(blk.ffn[0].bias), w_f2=w(blk.ffn[2].weight), b_f2=w(blk.ffn[2].bias),
                 mod=w(blk.modulation).reshape(6, self.dim))
+            if precision == "fp8":
+                for name in FP8_LINEARS:
+                    L["w8_" + name], L["s_" + name] = H.quant_rows_fp8(L["w_" + name])
+                    L["w_" + name] = None            # the bf16 copy is not read again
             self.layers.append(L)
             mods.append(L["mod"].data_ptr())
         self.mod_ptrs = torch.tensor(mods, dtype=torch.int64, device=self.device)
@@ -160,10 +175,16 @@ class DiTEngine:
         kpatch = self.in_dim * math.prod(self.patch_size)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
         self.x = e(nb, S, C, dt=F32)
-        self.h = e(M, C)
         self.qkv = e(nb, S, 3 * C)
         self.att = e(nb, S, C)
-        self.ffn = e(M, F)
+        if self.precision == "fp8":
+            self.h8, self.h_scale = e(M, C, dt=torch.uint8), e(M, dt=F32)
+            self.att8, self.att_scale = e(M, C, dt=torch.uint8), e(M, dt=F32)
+            self.ffn8 = e(M, F, dt=torch.uint8)
+            self.h = self.ffn = None
+        else:
+            self.h = e(M, C)
+            self.ffn = e(M, F)
         self.y = e(M, C, dt=F32)
         self.rows = e(n_tok, kpatch)
         self.sin = e(self.freq_dim, dt=F32)
@@ -268,11 +289,17 @@ class DiTEngine:
         v4 = self.qkv[:, :, 2 * C:].unflatten(2, (N, D))
         att4 = self.att.unflatten(2, (N, D))
         att2 = self.att.view(M, C)
+        fp8 = self.precision == "fp8"
         for l, L in enumerate(self.layers):
             mod = self.mod[l]
             # self-attention (model.py:242-246)
-            H.layernorm_modulate(x2, self.h, self.eps, shift=mod[0], scale=mod[1], round_norm=(l == 0))
-            H.gemm(self.h, L["w_qkv"], qkv2, L["b_qkv"], H.EPI_BF16)
+            if fp8:
+                H.layernorm_modulate_fp8(x2, self.h8, self.h_scale, self.eps, shift=mod[0], scale=mod[1],
+                                         round_norm=(l == 0))
+                H.gemm_fp8(self.h8, L["w8_qkv"], L["s_qkv"], qkv2, L["b_qkv"], H.EPI_BF16, a_scale=self.h_scale)
+            else:
+                H.layernorm_modulate(x2, self.h, self.eps, shift=mod[0], scale=mod[1], round_norm=(l == 0))
+                H.gemm(self.h, L["w_qkv"], qkv2, L["b_qkv"], H.EPI_BF16)
             for sl, nw in ((slice(0, C), L["nq"]), (slice(C, 2 * C), L["nk"])):
                 v_ = qkv2[:, sl]
                 H.rmsnorm_rope(v_, nw, v_, D, self.eps, rope=self.rope, rows_per_sample=S, tok_offset=row0,
@@ -281,20 +308,38 @@ class DiTEngine:
                 self._self_attention_sp()
             else:
                 self._self_attention(q4, k4, v4, att4)
-            H.gemm(att2, L["w_o"], x2, L["b_o"], H.EPI_RESID, gate=mod[2])
+            if fp8:
+                H.quant_rows_fp8(att2, self.att8, self.att_scale)
+                H.gemm_fp8(self.att8, L["w8_o"], L["s_o"], x2, L["b_o"], H.EPI_RESID, a_scale=self.att_scale,
+                           gate=mod[2])
+            else:
+                H.gemm(att2, L["w_o"], x2, L["b_o"], H.EPI_RESID, gate=mod[2])
             # cross-attention (model.py:250): local query rows against the replicated context K/V
-            H.layernorm_modulate(x2, self.h, self.eps, weight=L["n3w"], bias=L["n3b"])
             qc = qkv2[:, :C]
-            H.gemm(self.h, L["w_cq"], qc, L["b_cq"], H.EPI_BF16)
+            if fp8:
+                H.layernorm_modulate_fp8(x2, self.h8, self.h_scale, self.eps, weight=L["n3w"], bias=L["n3b"])
+                H.gemm_fp8(self.h8, L["w8_cq"], L["s_cq"], qc, L["b_cq"], H.EPI_BF16, a_scale=self.h_scale)
+            else:
+                H.layernorm_modulate(x2, self.h, self.eps, weight=L["n3w"], bias=L["n3b"])
+                H.gemm(self.h, L["w_cq"], qc, L["b_cq"], H.EPI_BF16)
             H.rmsnorm_rope(qc, L["cnq"], qc, D, self.eps)
             kvl = ctx.kv[l]
             H.flash_attn(q4, kvl[:, :, :C].unflatten(2, (N, D)), kvl[:, :, C:].unflatten(2, (N, D)), att4,
                          k_len=ctx.k_len, last_key_copies=ctx.last_key_copies)
-            H.gemm(att2, L["w_co"], x2, L["b_co"], H.EPI_RESID)
             # feed-forward (model.py:251-254)
-            H.layernorm_modulate(x2, self.h, self.eps, shift=mod[3], scale=mod[4])
-            H.gemm(self.h, L["w_f0"], self.ffn, L["b_f0"], H.EPI_BF16_GELU)
-            H.gemm(self.ffn, L["w_f2"], x2, L["b_f2"], H.EPI_RESID, gate=mod[5])
+            if fp8:
+                H.quant_rows_fp8(att2, self.att8, self.att_scale)
+                H.gemm_fp8(self.att8, L["w8_co"], L["s_co"], x2, L["b_co"], H.EPI_RESID, a_scale=self.att_scale)
+                H.layernorm_modulate_fp8(x2, self.h8, self.h_scale, self.eps, shift=mod[3], scale=mod[4])
+                H.gemm_fp8(self.h8, L["w8_f0"], L["s_f0"], self.ffn8, L["b_f0"], H.EPI_FP8_GELU, a_scale=self.h_scale,
+                           out_scale=self.ffn_act_scale)
+                H.gemm_fp8(self.ffn8, L["w8_f2"], L["s_f2"], x2, L["b_f2"], H.EPI_RESID,
+                           a_scale_all=self.ffn_act_scale, gate=mod[5])
+            else:
+                H.gemm(att2, L["w_co"], x2, L["b_co"], H.EPI_RESID)
+                H.layernorm_modulate(x2, self.h, self.eps, shift=mod[3], scale=mod[4])
+                H.gemm(self.h, L["w_f0"], self.ffn, L["b_f0"], H.EPI_BF16_GELU)
+                H.gemm(self.ffn, L["w_f2"], x2, L["b_f2"], H.EPI_RESID, gate=mod[5])
         # head + unpatchify (model.py:520-524)
         H.head_modulation(self.head_mod, self.e_vec, self.hmod)
         H.layernorm_modulate(x2, self.y, self.eps, shift=self.hmod[0], scale=self.hmod[1])

@@ -263,15 +263,19 @@ class WanModel(nn.Module):
         self._engine_key = None
         self._ctx_key = None
         self._ctx_cache = None
+        # "bf16" = the reference's arithmetic; "fp8" = e4m3 operands for the six large linear layers of
+        # every block (an extension: the reference has no such mode).  Takes effect at the next forward.
+        self.linear_precision = "bf16"
 
     # ---- engine management --------------------------------------------------------
     def _weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def engine(self):
-        key = self._weights_key()
+        key = (self._weights_key(), self.linear_precision)
         if self._engine is None or self._engine_key != key:
-            self._engine = DiTEngine(self)
+            self._engine = None                      # release the old copies before building new ones
+            self._engine = DiTEngine(self, precision=self.linear_precision)
             self._engine_key = key
             self._ctx_key = None
         return self._engine

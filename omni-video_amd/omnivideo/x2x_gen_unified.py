@@ -99,7 +99,10 @@ class OmniVideoX2XUnified:
     def __init__(self, config, checkpoint_dir, vlm_in_dim=4096, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False,
                  use_usp=False, sp_size=None, t5_cpu=False, use_visual_context_adapter=False,
                  visual_context_adapter_patch_size=(1, 4, 4), max_context_len=None, init_on_cpu=True,
-                 wan_config=None, fsdp_shard_size=None):
+                 wan_config=None, fsdp_shard_size=None, *, linear_precision="bf16"):
+        """linear_precision (extension): "bf16" = the reference's arithmetic; "fp8" runs the six large
+        linear layers of every DiT block on e4m3 operands (WanModel.linear_precision)."""
+        self.linear_precision = linear_precision
         self.device = torch.device(f"cuda:{device_id}")
         self.config, self.rank, self.t5_cpu, self.dit_fsdp, self.init_on_cpu = config, rank, t5_cpu, dit_fsdp, init_on_cpu
         if dit_fsdp or t5_fsdp:
@@ -178,7 +181,9 @@ class OmniVideoX2XUnified:
             wan_config=wan_config, vlm_in_dim=vlm_in_dim, precision_dtype=self.param_dtype,
             use_usp=self.use_usp, use_visual_context_adapter=use_vca,
             visual_context_adapter_patch_size=vca_patch, max_context_len=max_context_len, skip_init=True)
-        return m.to(self.param_dtype).to(self.device).eval()
+        m = m.to(self.param_dtype).to(self.device).eval()
+        m.wan_model.linear_precision = self.linear_precision
+        return m
 
     def _build_models(self, wan_config, checkpoint_dir, vlm_in_dim, use_vca, vca_patch, max_context_len):
         self.high_noise_model = self._new_model(wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len)

@@ -77,6 +77,29 @@ def gemm(M, N, K, epi=0, check=False, uniform=False):
     print(msg, flush=True)
 
 
+def gemm8(M, N, K, epi=0, check=False):
+    """e4m3 GEMM: operands quantised per row from the same distributions as gemm()."""
+    a = torch.randn(M, K, device="cuda").to(BF16)
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF16)
+    a8, sa = H.quant_rows_fp8(a)
+    w8, sw = H.quant_rows_fp8(w)
+    b = torch.randn(N, device="cuda").to(BF16)
+    dt = {0: BF16, 1: BF16, 2: torch.float32, 3: torch.float32, 4: torch.uint8}[epi]
+    out = torch.zeros(M, N, device="cuda", dtype=dt)
+    ms = timeit(lambda: H.gemm_fp8(a8, w8, sw, out, b, epi, a_scale=sa))
+    msg = f"gemm_fp8 M{M} N{N} K{K} epi{epi}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s"
+    if check:
+        out.zero_()
+        H.gemm_fp8(a8, w8, sw, out, b, epi, a_scale=sa)
+        f8 = torch.float8_e4m3fn
+        ref = (a8.view(f8).float() * sa[:, None]) @ (w8.view(f8).float() * sw[:, None]).t() + b.float()
+        full = a.float() @ w.float().t() + b.float()
+        err = (out.float() - ref.to(BF16).float()).abs().max().item()
+        rel = ((out.float() - full).norm() / full.norm()).item()
+        msg += f"  max|err| vs dequantised product {err:.3e}; rel L2 vs bf16-operand product {rel:.3e}"
+    print(msg, flush=True)
+
+
 def vae(latent=(16, 13, 60, 104), encode=False):
     """Full-width (dim 96) VAE decode (and encode) of one cfg2-sized latent, random weights."""
     import time
@@ -126,6 +149,17 @@ if __name__ == "__main__":
         gemm(4096, 4096, 4096, 0, uniform=True)
         gemm(8192, 8192, 8192, 0, uniform=True)
         gemm(8192, 8192, 8192, 0)
+    if "gemm8check" in args.what:
+        gemm8(1000, 512, 128, 0, check=True)
+        gemm8(777, 256, 192, 3, check=True)
+        gemm8(4096, 1536, 1536, 0, check=True)
+    if "gemm8" in args.what:
+        M = 40560
+        gemm8(M, 4608, 1536, 0)
+        gemm8(M, 1536, 1536, 3)
+        gemm8(M, 8960, 1536, 4)
+        gemm8(M, 1536, 8960, 3)
+        gemm8(8192, 8192, 8192, 0)
     if "gemm" in args.what:
         M = 40560
         gemm(M, 4608, 1536, 0)      # fused QKV
