@@ -91,6 +91,21 @@ int ovd_flash_attn_tail_fwd_bf16(const uint16_t* q, const uint16_t* k, const uin
                                  int64_t q_ld, int64_t k_ld, int64_t v_ld, int64_t o_ld, int64_t q_bs,
                                  int64_t k_bs, int64_t v_bs, int64_t o_bs, float softmax_scale, void* stream);
 
+/* The same operator with a caller-owned workspace that lets the library balance the last round of
+ * workgroups: when the grid of 256-row query blocks x heads x batch leaves at most half of the
+ * compute units busy in its final round, the trailing query blocks are computed by two workgroups
+ * each (one per half of the keys) and merged by a second small kernel; results then differ from
+ * the plain call only by fp32 summation order.  ovd_flash_attn_workspace_bytes (host function, no
+ * GPU work) returns the size that makes this possible for a shape (0 = it would not split); a NULL
+ * or smaller workspace gives exactly the plain call.  The workspace holds no state between calls.
+ * No counterpart in the reference (flash-attn allocates its own split buffers internally). */
+int64_t ovd_flash_attn_workspace_bytes(int B, int Lq, int N, int k_len);
+int ovd_flash_attn_ws_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, int B, int Lq,
+                               int Lk, int N, int head_dim, int k_len, int last_key_copies, int64_t q_ld,
+                               int64_t k_ld, int64_t v_ld, int64_t o_ld, int64_t q_bs, int64_t k_bs, int64_t v_bs,
+                               int64_t o_bs, float softmax_scale, void* workspace, int64_t workspace_bytes,
+                               void* stream);
+
 /* [Cin,T,H,W] (fp32, or bf16 when lat_is_bf16) -> bf16 rows [f*h*w, Cin*pt*ph*pw] in
  * (f,h,w) token order and (cin,pt,ph,pw) column order, ready for ovd_gemm_bf16 against
  * the flattened Conv3d weight.  Replaces the im2col half of nn.Conv3d with

@@ -225,12 +225,14 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
 #undef SOFTMAX_PAIR
 }
 
+constexpr int WS_VALUES = 66;      // per lane of a split workgroup: 64 accumulators, row maximum, row sum
+
 template <int NW>
 __device__ __forceinline__ void
 attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
               bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,
               long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias, int n_qblocks,
-              int n_heads, int n_batch) {
+              int n_heads, int n_batch, float* __restrict__ ws, int n_split, int k_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2] | V[2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -238,11 +240,24 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
     // with its own L2: when the (batch, head) pairs divide by 8, pair p is served entirely by
     // XCD p % 8 - consecutive workgroups of that XCD walk its query blocks - so a head's K/V
     // stream is fetched into one L2 instead of eight.
-    int qb, pair;
+    //
+    // Tail balancing: every workgroup runs for the same time (all keys), so a grid that is not a
+    // multiple of the CU count idles part of the chip during its last round.  The host may ask
+    // for the last n_split query blocks of every XCD to be served by two workgroups each, one
+    // per half of the keys (split at k_split); those write their unnormalised accumulators, row
+    // maximum and row sum to `ws`, and attn_merge_kernel combines the two halves.
+    int qb, pair, half = -1, s_idx = 0;
     {
         const int id = blockIdx.x, pairs = n_heads * n_batch;
         if ((pairs & 7) == 0) {
-            const int j = id >> 3;
+            int j = id >> 3;
+            const int n_full = (pairs >> 3) * n_qblocks - n_split;
+            if (j >= n_full) {
+                const int h = j - n_full;
+                half = h & 1;
+                s_idx = (id & 7) * n_split + (h >> 1);
+                j = n_full + (h >> 1);
+            }
             pair = (id & 7) + 8 * (j / n_qblocks);
             qb = j % n_qblocks;
         } else {
@@ -253,9 +268,18 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
     const int head = pair % n_heads, b = pair / n_heads;
     const int q0 = qb * (32 * NW) + wave * 32;
 
+    if (half == 0) {                 // keys [0, k_split): whole tiles, no tail
+        k_len = k_split;
+        tail_bias = 0.f;
+    }
+    const int k_begin = half == 1 ? k_split : 0;
+    if (half == 1) {                 // keys [k_split, k_len)
+        k_len -= k_split;
+        Lk -= k_split;
+    }
     const bf16_t* Qb = Q + b * q_bs + (long)head * HD;
-    const bf16_t* Kb = K + b * k_bs + (long)head * HD;
-    const bf16_t* Vb = V + b * v_bs + (long)head * HD;
+    const bf16_t* Kb = K + b * k_bs + (long)head * HD + (long)k_begin * k_ld;
+    const bf16_t* Vb = V + b * v_bs + (long)head * HD + (long)k_begin * v_ld;
 
     bf16x8 qf[8];
     {
@@ -356,6 +380,16 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
     PIPE_STEP(false, false, a0, a1, b0, b1, t);
 #undef PIPE_STEP
 
+    if (half >= 0) {                 // partial result in the register layout, [value][lane]: coalesced rows
+        float* w = ws + ((long)(s_idx * 2 + half) * NW + wave) * (WS_VALUES * 64) + lane;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[(db * 16 + j) * 64] = o_acc[db][j];
+        w[64 * 64] = m_c;
+        w[65 * 64] = half_sum(l_run);
+        return;
+    }
     const float inv = 1.0f / half_sum(l_run);
     const int qr = q0 + l31;
     if (qr < Lq) {
@@ -377,15 +411,76 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
         const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,       \
         bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,   \
         long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias, int n_qblocks,    \
-        int n_heads, int n_batch) {                                                                      \
+        int n_heads, int n_batch, float* __restrict__ ws, int n_split, int k_split) {                    \
         attn_fwd_pipe<NW>(Q, K, V, O, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs,     \
-                          scale_log2, tail_bias, n_qblocks, n_heads, n_batch);                           \
+                          scale_log2, tail_bias, n_qblocks, n_heads, n_batch, ws, n_split, k_split);     \
     }
 ATTN_KERNEL(4)
 ATTN_KERNEL(8)
 #undef ATTN_KERNEL
 
+// Combines the two key halves of the split query blocks: one 64-lane block per (split block, wave),
+// every lane in the role it had in the attention kernel.  (o, m, l) of a half are relative to its own
+// reference maximum m: o = o0 2^(m0-m) + o1 2^(m1-m), l likewise, out = o / l.
+__global__ void __launch_bounds__(64) attn_merge_kernel(const float* __restrict__ ws, bf16_t* __restrict__ O, int Lq,
+                                                        long o_ld, long o_bs, int n_qblocks, int n_heads, int n_batch,
+                                                        int n_split, int nw) {
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int s_idx = blockIdx.x / nw, wave = blockIdx.x % nw;
+    const int xcd = s_idx / n_split;
+    const int j = ((n_heads * n_batch) >> 3) * n_qblocks - n_split + s_idx % n_split;
+    const int pair = xcd + 8 * (j / n_qblocks), qb = j % n_qblocks;
+    const int head = pair % n_heads, b = pair / n_heads;
+    const int qr = qb * (32 * nw) + wave * 32 + l31;
+    const float* w0 = ws + ((long)(s_idx * 2) * nw + wave) * (WS_VALUES * 64) + lane;
+    const float* w1 = w0 + (long)nw * (WS_VALUES * 64);
+    const float m0 = w0[64 * 64], m1 = w1[64 * 64];
+    const float m = fmaxf(m0, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m0 - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+    const float inv = 1.0f / (w0[65 * 64] * a0 + w1[65 * 64] * a1);
+    if (qr >= Lq) return;
+    bf16_t* op = O + b * o_bs + (long)qr * o_ld + (long)head * HD + 4 * hi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (db * 16 + 4 * g4 + i) * 64;
+                y[i] = (w0[r] * a0 + w1[r] * a1) * inv;
+            }
+            uint2 w;
+            w.x = pack_bf2(y[0], y[1]);
+            w.y = pack_bf2(y[2], y[3]);
+            *reinterpret_cast<uint2*>(op + db * 32 + 8 * g4) = w;
+        }
+}
+
 }  // namespace
+
+// Plan of the tail balancing for an 8-wave grid: the number of query blocks per XCD to split in two
+// (0 = none).  Worth it when the last round of workgroups would fill at most half of the CUs.
+static int attn_split_plan(int B, int Lq, int N, int k_len) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const long pairs = (long)B * N, nwg = pairs * ceil_div(Lq, 256);
+    if ((pairs & 7) || (cus & 7) || k_len < 16 * BKV) return 0;
+    const long rounds = nwg / cus, rem = nwg % cus;
+    if (rounds < 1 || rounds > 32 || rem == 0 || rem > cus / 2 || (rem & 7)) return 0;
+    return (int)(rem / 8);
+}
+
+// bytes of workspace with which ovd_impl_attn_fwd can balance its last round (0: it would not split)
+long ovd_impl_attn_workspace_bytes(int B, int Lq, int N, int k_len) {
+    if ((long)ceil_div(Lq, 256) * N * B < 256) return 0;
+    return (long)attn_split_plan(B, Lq, N, k_len) * 8 * 2 * 8 * (WS_VALUES * 64) * (long)sizeof(float);
+}
 
 // q [B,Lq,N,128], k/v [B,Lk,N,128], out [B,Lq,N,128]; *_ld = elements between
 // consecutive tokens, *_bs = elements between batch entries (so the fused QKV
@@ -393,7 +488,8 @@ ATTN_KERNEL(8)
 // k_len - 1 counts last_key_copies times (a run of identical trailing keys folded into one).
 int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Lq, int Lk,
                       int N, int D, int k_len, long q_ld, long k_ld, long v_ld, long o_ld, long q_bs, long k_bs,
-                      long v_bs, long o_bs, float softmax_scale, int last_key_copies, hipStream_t st) {
+                      long v_bs, long o_bs, float softmax_scale, int last_key_copies, void* workspace,
+                      long workspace_bytes, hipStream_t st) {
     OVD_REQUIRE(D == HD, "attention: head_dim %d not supported (only 128)", D);
     OVD_REQUIRE(B > 0 && N > 0 && Lq > 0 && Lk > 0, "attention: empty problem B=%d N=%d Lq=%d Lk=%d", B, N, Lq, Lk);
     OVD_REQUIRE(k_len > 0 && k_len <= Lk, "attention: k_len=%d outside (0, Lk=%d]", k_len, Lk);
@@ -417,6 +513,13 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
     }
     const bool small = (long)ceil_div(Lq, 256) * N * B < 256;
     const int waves = forced == 4 || forced == 8 ? forced : (small ? 4 : 8);
+    // tail balancing needs the caller's workspace (ovd_impl_attn_workspace_bytes); without it: plain grid
+    int n_split = 0, k_split = 0;
+    if (waves == 8 && workspace != nullptr) {
+        n_split = attn_split_plan(B, Lq, N, k_len);
+        if ((long)n_split * 8 * 2 * 8 * (WS_VALUES * 64) * (long)sizeof(float) > workspace_bytes) n_split = 0;
+        k_split = (ceil_div(k_len, BKV) / 2) * BKV;
+    }
 #define ATTN_CASE(KERNEL, NW)                                                                              \
     {                                                                                                      \
         static bool attr_set = false;                                                                      \
@@ -427,10 +530,14 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
             attr_set = true;                                                                               \
         }                                                                                                  \
         const int nqb = ceil_div(Lq, 32 * NW);                                                             \
-        OVD_REQUIRE((long)nqb * N * B < (1L << 31), "attention: grid too large");                          \
-        dim3 grid(nqb * N * B), blk(64 * NW);                                                              \
+        OVD_REQUIRE((long)nqb * N * B + 8L * n_split < (1L << 31), "attention: grid too large");           \
+        dim3 grid(nqb * N * B + 8 * n_split), blk(64 * NW);                                                \
         hipLaunchKernelGGL(KERNEL, grid, blk, lds, st, q, k, v, out, Lq, Lk, k_len, q_ld, k_ld, v_ld,      \
-                           o_ld, q_bs, k_bs, v_bs, o_bs, scale_log2, tail_bias, nqb, N, B);                \
+                           o_ld, q_bs, k_bs, v_bs, o_bs, scale_log2, tail_bias, nqb, N, B,                 \
+                           (float*)workspace, n_split, k_split);                                           \
+        if (n_split > 0)                                                                                   \
+            hipLaunchKernelGGL(attn_merge_kernel, dim3(8 * n_split * NW), dim3(64), 0, st,                 \
+                               (const float*)workspace, out, Lq, o_ld, o_bs, nqb, N, B, n_split, NW);      \
     }
     if (waves == 8) ATTN_CASE(attn_pipe_kernel_w8, 8) else ATTN_CASE(attn_pipe_kernel_w4, 4)
 #undef ATTN_CASE

@@ -21,6 +21,9 @@ SIGNATURES = {
     "ovd_gemm_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _p],
     "ovd_flash_attn_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p],
     "ovd_flash_attn_tail_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p],
+    "ovd_flash_attn_ws_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p,
+                                   _l, _p],
+    "ovd_flash_attn_workspace_bytes": [_i, _i, _i, _i],
     "ovd_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_time_sinusoid": [_p, _p, _i, _p, _i, _p],
     "ovd_gemv_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -65,7 +68,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = _i
+            fn.restype = _l if name == "ovd_flash_attn_workspace_bytes" else _i
         _lib = L
     return _lib
 
@@ -164,11 +167,17 @@ def gemm(a, w, out, bias=None, epilogue=EPI_BF16, gate=None):
     return out
 
 
-def flash_attn(q, k, v, out, k_len=None, softmax_scale=None, last_key_copies=1):
+def flash_attn_workspace_bytes(B, Lq, N, k_len):
+    """Bytes of workspace with which flash_attn balances its last round of workgroups (0: no use)."""
+    return int(lib().ovd_flash_attn_workspace_bytes(int(B), int(Lq), int(N), int(k_len)))
+
+
+def flash_attn(q, k, v, out, k_len=None, softmax_scale=None, last_key_copies=1, workspace=None):
     """q [B,Lq,N,D], k/v [B,Lk,N,D], out [B,Lq,N,D] bf16; the (N,D) dims must be dense, the
     token and batch dims may be strided (views into a fused projection buffer).  Keys at or
     beyond k_len are masked; key k_len - 1 counts last_key_copies times (a run of identical
-    trailing keys folded into one)."""
+    trailing keys folded into one).  workspace: a device byte buffer of
+    flash_attn_workspace_bytes(...) bytes (optional; see the header)."""
     B, Lq, N, D = q.shape
     Lk = k.shape[1]
     for t in (q, k, v, out):
@@ -178,6 +187,14 @@ def flash_attn(q, k, v, out, k_len=None, softmax_scale=None, last_key_copies=1):
         raise ValueError("attention: shape mismatch")
     scale = float(softmax_scale) if softmax_scale is not None else D ** -0.5
     kl = int(Lk if k_len is None else k_len)
+    if workspace is not None:
+        if not workspace.is_cuda or not workspace.is_contiguous():
+            raise ValueError("attention: workspace must be a contiguous device tensor")
+        _call("ovd_flash_attn_ws_fwd_bf16", _ptr(q, BF16), _ptr(k, BF16), _ptr(v, BF16), _ptr(out, BF16), B, Lq, Lk,
+              N, D, kl, int(last_key_copies), q.stride(1), k.stride(1), v.stride(1), out.stride(1), q.stride(0),
+              k.stride(0), v.stride(0), out.stride(0), scale, workspace.data_ptr(),
+              workspace.numel() * workspace.element_size(), _stream())
+        return out
     if int(last_key_copies) != 1:
         _call("ovd_flash_attn_tail_fwd_bf16", _ptr(q, BF16), _ptr(k, BF16), _ptr(v, BF16), _ptr(out, BF16), B, Lq, Lk,
               N, D, kl, int(last_key_copies), q.stride(1), k.stride(1), v.stride(1), out.stride(1), q.stride(0),

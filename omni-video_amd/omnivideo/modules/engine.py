@@ -193,6 +193,9 @@ class DiTEngine:
         self.mod = e(self.num_layers, 6, C, dt=F32)
         self.hmod = e(2, C, dt=F32)
         self.rope = build_rope_table(self.head_dim, max(grid), dev)
+        # self-attention runs over the full sequence for N / sp heads: workspace for its tail balancing
+        ws = H.flash_attn_workspace_bytes(nb, seq_len, N // sp, n_tok)
+        self.attn_ws = torch.empty(ws, dtype=torch.uint8, device=dev) if ws > 0 else None
         if sp > 1:
             Cs = C // sp
             self.sp_send = e(sp, 3, nb, S, Cs)        # q|k|v of my rows, split by destination head group
@@ -234,7 +237,7 @@ class DiTEngine:
         if self.timing is not None:      # profiling hook: events around the dominant kernel
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        H.flash_attn(q4, k4, v4, att4, k_len=self.n_tok)
+        H.flash_attn(q4, k4, v4, att4, k_len=self.n_tok, workspace=self.attn_ws)
         if self.timing is not None:
             ev[1].record()
             self.timing.append(ev)

@@ -287,3 +287,30 @@ def test_head_unpatchify(H):
     H.head_unpatchify(y, dev(sd["wan_model.head.head.weight"], BF16), dev(sd["wan_model.head.head.bias"], BF16), out,
                       grid, cfg["patch_size"], cfg["out_dim"])
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,L,k_len,copies", [(1, 8, 10240, 10240, 1), (1, 8, 10200, 9999, 1), (2, 4, 10240, 8000, 37),
+                                                (2, 12, 20280, 20280, 1)])
+def test_attention_tail_balancing_equals_plain_call(H, B, N, L, k_len, copies):
+    """With a workspace the trailing query blocks are computed in two key halves and merged: the
+    result equals the plain call up to fp32 summation order, and rows outside the split blocks are
+    bitwise unchanged."""
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + N)
+    q, k, v = (torch.randn(B, L, N, 128, device="cuda", generator=g).to(BF16) for _ in range(3))
+    nbytes = H.flash_attn_workspace_bytes(B, L, N, k_len)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    plain, bal = torch.empty_like(q), torch.full_like(q, float("nan"))
+    H.flash_attn(q, k, v, plain, k_len=k_len, last_key_copies=copies)
+    H.flash_attn(q, k, v, bal, k_len=k_len, last_key_copies=copies, workspace=ws)
+    assert torch.isfinite(bal.float()).all()
+    d = (bal.float() - plain.float()).abs()
+    assert float(d.max()) < 2e-2 and float((d > 0).float().mean()) < 0.2     # a few last-bit differences in the split rows
+    changed = (d.amax(dim=(0, 2, 3)) > 0).nonzero().flatten()
+    assert changed.numel() > 0 and int(changed.min()) >= L // 2              # only trailing query blocks are split
+    # too small a workspace, or none: exactly the plain call
+    small = torch.full_like(q, float("nan"))
+    H.flash_attn(q, k, v, small, k_len=k_len, last_key_copies=copies, workspace=ws[:1024])
+    assert torch.equal(small, plain)
+    # shapes that do not profit report 0
+    assert H.flash_attn_workspace_bytes(1, 1024, 2, 1024) == 0 and H.flash_attn_workspace_bytes(2, 75600, 40, 75600) == 0

@@ -27,7 +27,7 @@ def timeit(fn, iters=10, warm=2):
     return a.elapsed_time(b) / iters
 
 
-def attn(B, Lq, Lk, N, k_len=None, check=False, strided_q=False, fused_kv=False, same_rows=0):
+def attn(B, Lq, Lk, N, k_len=None, check=False, strided_q=False, fused_kv=False, same_rows=0, balance=False):
     D = 128
     if strided_q:      # q addressed inside a fused [B, Lq, 3*N*D] projection buffer
         q = torch.randn(B, Lq, 3 * N * D, device="cuda").to(BF16)[:, :, :N * D].unflatten(2, (N, D))
@@ -41,9 +41,13 @@ def attn(B, Lq, Lk, N, k_len=None, check=False, strided_q=False, fused_kv=False,
             kv[:, same_rows:] = kv[:, same_rows:same_rows + 1]
         k, v = kv[:, :, :N * D].unflatten(2, (N, D)), kv[:, :, N * D:].unflatten(2, (N, D))
     o = torch.empty(B, Lq, N, D, device="cuda", dtype=BF16)
-    ms = timeit(lambda: H.flash_attn(q, k, v, o, k_len=k_len))
+    ws = None
+    if balance:
+        nbytes = H.flash_attn_workspace_bytes(B, Lq, N, k_len or Lk)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if nbytes else None
+    ms = timeit(lambda: H.flash_attn(q, k, v, o, k_len=k_len, workspace=ws))
     fl = 4.0 * B * N * Lq * (k_len or Lk) * D
-    msg = f"attn B{B} Lq{Lq} Lk{Lk} N{N}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s"
+    msg = f"attn B{B} Lq{Lq} Lk{Lk} N{N}{' balanced' if ws is not None else ''}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s"
     if check:
         ref = torch.nn.functional.scaled_dot_product_attention(
             q.transpose(1, 2).float(), k.transpose(1, 2).float()[:, :, :k_len], v.transpose(1, 2).float()[:, :, :k_len])
@@ -133,6 +137,7 @@ if __name__ == "__main__":
     if "attn" in args.what:
         attn(1, 1024, 1024, 2, 1000, check=True)
         attn(2, 20280, 20280, 12)
+        attn(2, 20280, 20280, 12, balance=True)
         attn(2, 20280, 6144, 12)
     if "xattn" in args.what:
         attn(2, 20280, 512, 12)
