@@ -42,6 +42,18 @@ int ovd_layernorm_modulate_f32(const float* x, int64_t ldx, const float* shift, 
                                const uint16_t* weight, const uint16_t* bias, float* out, int64_t ldo,
                                int M, int C, float eps, int round_norm, void* stream);
 
+/* The same LayerNorm (+ affine) (+ modulation) with the residual update that precedes it in the block
+ * applied on the way in: x[m][c] += res[m][c] * res_gate[c] (res_gate NULL = 1), x written back, then
+ * normalised.  res is the bf16 output of the layer's last Linear (ovd_gemm_bf16, epilogue 0), so
+ * `x = x + y * e` of WanAttentionBlock.forward (omnivideo/modules/model.py:245-246, 250, 253-254) and the
+ * norm that follows (:243, :250, :252; Head.forward :287-289) make one pass over x instead of two.
+ * Results equal epilogue 3 of ovd_gemm_bf16 followed by ovd_layernorm_modulate_* bit for bit.
+ * out_kind: 0 = bf16 out, 1 = fp32 out, 2 = e4m3 out + row_scale[M] (ovd_layernorm_modulate_fp8). */
+int ovd_resid_layernorm_modulate(float* x, int64_t ldx, const uint16_t* res, int64_t ldr, const float* res_gate,
+                                 const float* shift, const float* scale, const uint16_t* weight, const uint16_t* bias,
+                                 void* out, int64_t ldo, int out_kind, float* row_scale, int M, int C, float eps,
+                                 int round_norm, void* stream);
+
 /* RMSNorm over the FULL row (all heads) with bf16 weight, then optional 3-axis
  * interleaved-pair rotary embedding, bf16 in / bf16 out (in-place allowed).
  * rope: float2 (cos,sin) table [3][rope_rows][D/2] or NULL for no rotation; the token

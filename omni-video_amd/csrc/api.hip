@@ -13,10 +13,10 @@ void ovd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-int ovd_impl_ln_bf16(const float*, long, const float*, const float*, const bf16_t*, const bf16_t*, bf16_t*, long,
-                     int, int, float, int, hipStream_t);
-int ovd_impl_ln_f32(const float*, long, const float*, const float*, const bf16_t*, const bf16_t*, float*, long, int,
-                    int, float, int, hipStream_t);
+int ovd_impl_ln_bf16(float*, long, const bf16_t*, long, const float*, const float*, const float*, const bf16_t*,
+                     const bf16_t*, bf16_t*, long, int, int, float, int, hipStream_t);
+int ovd_impl_ln_f32(float*, long, const bf16_t*, long, const float*, const float*, const float*, const bf16_t*,
+                    const bf16_t*, float*, long, int, int, float, int, hipStream_t);
 int ovd_impl_rmsnorm_rope(const bf16_t*, long, const bf16_t*, const float*, int, bf16_t*, long, int, int, int, float,
                           int, int, int, int, int, int, hipStream_t);
 int ovd_impl_gemm_bf16(const bf16_t*, long, const bf16_t*, long, const bf16_t*, void*, long, const float*, int, int,
@@ -27,8 +27,8 @@ long ovd_impl_attn_workspace_bytes(int, int, int, int);
 int ovd_impl_to_uint8(const float*, uint8_t*, long, long, int, long, float, float, hipStream_t);
 int ovd_impl_resize_coeffs(int, int, int*, int*, int);
 int ovd_impl_quant_rows_fp8(const bf16_t*, long, uint8_t*, long, float*, int, int, hipStream_t);
-int ovd_impl_ln_fp8(const float*, long, const float*, const float*, const bf16_t*, const bf16_t*, uint8_t*, long, float*,
-                    int, int, float, int, hipStream_t);
+int ovd_impl_ln_fp8(float*, long, const bf16_t*, long, const float*, const float*, const float*, const bf16_t*,
+                    const bf16_t*, uint8_t*, long, float*, int, int, float, int, hipStream_t);
 int ovd_impl_gemm_fp8(const uint8_t*, long, const float*, float, const uint8_t*, long, const float*, const bf16_t*, void*,
                       long, const float*, float, int, int, int, int, hipStream_t);
 int ovd_impl_frames_resize(const uint8_t*, uint8_t*, float*, const int*, const int*, int, const int*, const int*, int,
@@ -70,7 +70,8 @@ int ovd_layernorm_modulate_bf16(const float* x, int64_t ldx, const float* shift,
                                 int C, float eps, int round_norm, void* stream) {
     NONNULL(x); NONNULL(out);
     OVD_REQUIRE(M >= 0 && C > 0, "layernorm: bad shape M=%d C=%d", M, C);
-    return ovd_impl_ln_bf16(x, ldx, shift, scale, weight, bias, out, ldo, M, C, eps, round_norm, ST(stream));
+    return ovd_impl_ln_bf16(const_cast<float*>(x), ldx, nullptr, 0, nullptr, shift, scale, weight, bias, out, ldo, M, C,
+                            eps, round_norm, ST(stream));
 }
 
 int ovd_layernorm_modulate_f32(const float* x, int64_t ldx, const float* shift, const float* scale,
@@ -78,7 +79,8 @@ int ovd_layernorm_modulate_f32(const float* x, int64_t ldx, const float* shift, 
                                float eps, int round_norm, void* stream) {
     NONNULL(x); NONNULL(out);
     OVD_REQUIRE(M >= 0 && C > 0, "layernorm: bad shape M=%d C=%d", M, C);
-    return ovd_impl_ln_f32(x, ldx, shift, scale, weight, bias, out, ldo, M, C, eps, round_norm, ST(stream));
+    return ovd_impl_ln_f32(const_cast<float*>(x), ldx, nullptr, 0, nullptr, shift, scale, weight, bias, out, ldo, M, C,
+                           eps, round_norm, ST(stream));
 }
 
 int ovd_rmsnorm_rope_bf16(const uint16_t* in, int64_t ldi, const uint16_t* weight, const float* rope, int rope_rows,
@@ -204,8 +206,30 @@ int ovd_layernorm_modulate_fp8(const float* x, int64_t ldx, const float* shift, 
                                const void* bias, uint8_t* out, int64_t ldo, float* row_scale, int M, int C, float eps,
                                int round_norm, void* stream) {
     NONNULL(x); NONNULL(out); NONNULL(row_scale);
-    return ovd_impl_ln_fp8(x, ldx, shift, scale, (const bf16_t*)weight, (const bf16_t*)bias, out, ldo, row_scale, M, C,
-                           eps, round_norm, ST(stream));
+    return ovd_impl_ln_fp8(const_cast<float*>(x), ldx, nullptr, 0, nullptr, shift, scale, (const bf16_t*)weight,
+                           (const bf16_t*)bias, out, ldo, row_scale, M, C, eps, round_norm, ST(stream));
+}
+
+int ovd_resid_layernorm_modulate(float* x, int64_t ldx, const uint16_t* res, int64_t ldr, const float* res_gate,
+                                 const float* shift, const float* scale, const uint16_t* weight, const uint16_t* bias,
+                                 void* out, int64_t ldo, int out_kind, float* row_scale, int M, int C, float eps,
+                                 int round_norm, void* stream) {
+    NONNULL(x); NONNULL(res); NONNULL(out);
+    OVD_REQUIRE(M >= 0 && C > 0, "layernorm: bad shape M=%d C=%d", M, C);
+    switch (out_kind) {
+        case 0:
+            return ovd_impl_ln_bf16(x, ldx, res, ldr, res_gate, shift, scale, weight, bias, (bf16_t*)out, ldo, M, C, eps,
+                                    round_norm, ST(stream));
+        case 1:
+            return ovd_impl_ln_f32(x, ldx, res, ldr, res_gate, shift, scale, weight, bias, (float*)out, ldo, M, C, eps,
+                                   round_norm, ST(stream));
+        case 2:
+            NONNULL(row_scale);
+            return ovd_impl_ln_fp8(x, ldx, res, ldr, res_gate, shift, scale, weight, bias, (uint8_t*)out, ldo, row_scale,
+                                   M, C, eps, round_norm, ST(stream));
+        default:
+            OVD_FAIL("layernorm: out_kind %d is not 0 (bf16), 1 (fp32) or 2 (e4m3 + row scales)", out_kind);
+    }
 }
 
 int ovd_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, float a_scale_all, const uint8_t* W, int64_t ldw,

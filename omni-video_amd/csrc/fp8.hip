@@ -81,8 +81,10 @@ __global__ void __launch_bounds__(256) quant_rows_fp8_kernel(const bf16_t* __res
 
 // LayerNorm (+ affine) (+ modulation) as ln_mod_kernel of norm.hip computes it, rounded to bf16 as
 // that kernel's output is, then quantised per row.
-template <int VPL>
-__global__ void __launch_bounds__(256) ln_mod_fp8_kernel(const float* __restrict__ x, long ldx,
+template <int VPL, bool RES>
+__global__ void __launch_bounds__(256) ln_mod_fp8_kernel(float* __restrict__ x, long ldx,
+                                                         const bf16_t* __restrict__ res, long ldr,
+                                                         const float* __restrict__ res_gate,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ scale,
                                                          const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
@@ -92,12 +94,22 @@ __global__ void __launch_bounds__(256) ln_mod_fp8_kernel(const float* __restrict
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
+    float4* xr = reinterpret_cast<float4*>(x + (long)row * ldx);
     float4 v[VPL];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         v[i] = xr[i * 64 + lane];
+        if (RES) {                       // pending residual update, as in ln_mod_kernel of norm.hip
+            const uint2 rp = *reinterpret_cast<const uint2*>(res + (long)row * ldr + (i * 64 + lane) * 4);
+            float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (res_gate) g = *reinterpret_cast<const float4*>(res_gate + (i * 64 + lane) * 4);
+            v[i].x = fmaf(bf2f(rp.x & 0xffff), g.x, v[i].x);
+            v[i].y = fmaf(bf2f(rp.x >> 16), g.y, v[i].y);
+            v[i].z = fmaf(bf2f(rp.y & 0xffff), g.z, v[i].z);
+            v[i].w = fmaf(bf2f(rp.y >> 16), g.w, v[i].w);
+            xr[i * 64 + lane] = v[i];
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / (float)C;
@@ -346,10 +358,12 @@ int ovd_impl_quant_rows_fp8(const bf16_t* x, long ldx, uint8_t* q, long ldq, flo
     return 0;
 }
 
-int ovd_impl_ln_fp8(const float* x, long ldx, const float* shift, const float* scale, const bf16_t* w,
-                    const bf16_t* b, uint8_t* out, long ldo, float* row_scale, int M, int C, float eps,
-                    int round_norm, hipStream_t st) {
+int ovd_impl_ln_fp8(float* x, long ldx, const bf16_t* res, long ldr, const float* res_gate, const float* shift,
+                    const float* scale, const bf16_t* w, const bf16_t* b, uint8_t* out, long ldo, float* row_scale,
+                    int M, int C, float eps, int round_norm, hipStream_t st) {
     OVD_REQUIRE(C % 256 == 0, "layernorm fp8: C=%d must be a multiple of 256", C);
+    OVD_REQUIRE(res != nullptr || res_gate == nullptr, "layernorm fp8: residual gate without a residual");
+    OVD_REQUIRE(res == nullptr || (ldr % 4 == 0 && ldr >= C), "layernorm fp8: bad residual row stride");
     OVD_REQUIRE((w == nullptr) == (b == nullptr), "layernorm fp8: weight and bias must come together");
     OVD_REQUIRE((scale == nullptr) == (shift == nullptr), "layernorm fp8: scale and shift must come together");
     OVD_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "layernorm fp8: row strides must be multiples of 4");
@@ -357,8 +371,12 @@ int ovd_impl_ln_fp8(const float* x, long ldx, const float* shift, const float* s
     dim3 grid(ceil_div(M, 4)), blk(256);
 #define LN_CASE(V)                                                                                          \
     case V:                                                                                                 \
-        hipLaunchKernelGGL((ln_mod_fp8_kernel<V>), grid, blk, 0, st, x, ldx, shift, scale, w, b, out, ldo,     \
-                           row_scale, M, C, eps, round_norm);                                               \
+        if (res)                                                                                            \
+            hipLaunchKernelGGL((ln_mod_fp8_kernel<V, true>), grid, blk, 0, st, x, ldx, res, ldr, res_gate,     \
+                               shift, scale, w, b, out, ldo, row_scale, M, C, eps, round_norm);             \
+        else                                                                                                \
+            hipLaunchKernelGGL((ln_mod_fp8_kernel<V, false>), grid, blk, 0, st, x, ldx, res, ldr, res_gate,    \
+                               shift, scale, w, b, out, ldo, row_scale, M, C, eps, round_norm);             \
         break;
     switch (C / 256) {
         LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(6) LN_CASE(8) LN_CASE(12) LN_CASE(16) LN_CASE(20)

@@ -10,8 +10,14 @@
 // modulation of WanAttentionBlock.forward (:243,252) and Head.forward (:287-289).
 // round_norm: the block-0 case where the LayerNorm input is a bf16 tensor and the
 // normalised value is cast back to bf16 before the modulation.
-template <int VPL, typename OutT>
-__global__ void __launch_bounds__(256) ln_mod_kernel(const float* __restrict__ x, long ldx,
+// RES: the pending residual update of the layer before this norm is applied on the way in,
+// x[m][c] += res[m][c] * res_gate[c] (res bf16 = the rounded output of that layer's last Linear,
+// model.py:245-246,250,253-254), written back to x and then normalised - one pass over x
+// instead of a read-modify-write in the GEMM epilogue followed by this kernel's read.
+template <int VPL, typename OutT, bool RES>
+__global__ void __launch_bounds__(256) ln_mod_kernel(float* __restrict__ x, long ldx,
+                                                     const bf16_t* __restrict__ res, long ldr,
+                                                     const float* __restrict__ res_gate,
                                                      const float* __restrict__ shift,
                                                      const float* __restrict__ scale,
                                                      const bf16_t* __restrict__ w,
@@ -20,12 +26,22 @@ __global__ void __launch_bounds__(256) ln_mod_kernel(const float* __restrict__ x
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
+    float4* xr = reinterpret_cast<float4*>(x + (long)row * ldx);
     float4 v[VPL];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         v[i] = xr[i * 64 + lane];
+        if (RES) {
+            const uint2 rp = *reinterpret_cast<const uint2*>(res + (long)row * ldr + (i * 64 + lane) * 4);
+            float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (res_gate) g = *reinterpret_cast<const float4*>(res_gate + (i * 64 + lane) * 4);
+            v[i].x = fmaf(bf2f(rp.x & 0xffff), g.x, v[i].x);
+            v[i].y = fmaf(bf2f(rp.x >> 16), g.y, v[i].y);
+            v[i].z = fmaf(bf2f(rp.y & 0xffff), g.z, v[i].z);
+            v[i].w = fmaf(bf2f(rp.y >> 16), g.w, v[i].w);
+            xr[i * 64 + lane] = v[i];
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / (float)C;
@@ -73,19 +89,25 @@ __global__ void __launch_bounds__(256) ln_mod_kernel(const float* __restrict__ x
 }
 
 template <typename OutT>
-static int launch_ln(const float* x, long ldx, const float* shift, const float* scale, const bf16_t* w,
-                     const bf16_t* b, OutT* out, long ldo, int M, int C, float eps, int round_norm,
-                     hipStream_t st) {
+static int launch_ln(float* x, long ldx, const bf16_t* res, long ldr, const float* res_gate, const float* shift,
+                     const float* scale, const bf16_t* w, const bf16_t* b, OutT* out, long ldo, int M, int C,
+                     float eps, int round_norm, hipStream_t st) {
     OVD_REQUIRE(C % 256 == 0, "layernorm: C=%d must be a multiple of 256", C);
+    OVD_REQUIRE(res != nullptr || res_gate == nullptr, "layernorm: residual gate without a residual");
+    OVD_REQUIRE(res == nullptr || (ldr % 4 == 0 && ldr >= C), "layernorm: bad residual row stride");
     OVD_REQUIRE((w == nullptr) == (b == nullptr), "layernorm: weight and bias must come together");
     OVD_REQUIRE((scale == nullptr) == (shift == nullptr), "layernorm: scale and shift must come together");
     OVD_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "layernorm: row strides must be multiples of 4");
     if (M == 0) return 0;
     dim3 grid(ceil_div(M, 4)), blk(256);
-#define LN_CASE(V)                                                                                   \
-    case V:                                                                                          \
-        hipLaunchKernelGGL((ln_mod_kernel<V, OutT>), grid, blk, 0, st, x, ldx, shift, scale, w, b, out, \
-                           ldo, M, C, eps, round_norm);                                              \
+#define LN_CASE(V)                                                                                         \
+    case V:                                                                                                \
+        if (res)                                                                                           \
+            hipLaunchKernelGGL((ln_mod_kernel<V, OutT, true>), grid, blk, 0, st, x, ldx, res, ldr, res_gate,  \
+                               shift, scale, w, b, out, ldo, M, C, eps, round_norm);                       \
+        else                                                                                               \
+            hipLaunchKernelGGL((ln_mod_kernel<V, OutT, false>), grid, blk, 0, st, x, ldx, res, ldr, res_gate, \
+                               shift, scale, w, b, out, ldo, M, C, eps, round_norm);                       \
         break;
     switch (C / 256) {
         LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(6) LN_CASE(8) LN_CASE(12) LN_CASE(16) LN_CASE(20)
@@ -97,15 +119,16 @@ static int launch_ln(const float* x, long ldx, const float* shift, const float* 
     return 0;
 }
 
-int ovd_impl_ln_bf16(const float* x, long ldx, const float* shift, const float* scale, const bf16_t* w,
-                     const bf16_t* b, bf16_t* out, long ldo, int M, int C, float eps, int round_norm,
-                     hipStream_t st) {
-    return launch_ln<bf16_t>(x, ldx, shift, scale, w, b, out, ldo, M, C, eps, round_norm, st);
+// x is written only when a residual is given
+int ovd_impl_ln_bf16(float* x, long ldx, const bf16_t* res, long ldr, const float* res_gate, const float* shift,
+                     const float* scale, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int M, int C,
+                     float eps, int round_norm, hipStream_t st) {
+    return launch_ln<bf16_t>(x, ldx, res, ldr, res_gate, shift, scale, w, b, out, ldo, M, C, eps, round_norm, st);
 }
-int ovd_impl_ln_f32(const float* x, long ldx, const float* shift, const float* scale, const bf16_t* w,
-                    const bf16_t* b, float* out, long ldo, int M, int C, float eps, int round_norm,
-                    hipStream_t st) {
-    return launch_ln<float>(x, ldx, shift, scale, w, b, out, ldo, M, C, eps, round_norm, st);
+int ovd_impl_ln_f32(float* x, long ldx, const bf16_t* res, long ldr, const float* res_gate, const float* shift,
+                    const float* scale, const bf16_t* w, const bf16_t* b, float* out, long ldo, int M, int C,
+                    float eps, int round_norm, hipStream_t st) {
+    return launch_ln<float>(x, ldx, res, ldr, res_gate, shift, scale, w, b, out, ldo, M, C, eps, round_norm, st);
 }
 
 // ---------------------------------------------------------------------------------

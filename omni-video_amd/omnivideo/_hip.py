@@ -33,6 +33,7 @@ SIGNATURES = {
     "ovd_cfg_unipc_step": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
     "ovd_cfg_dpm_step": [_p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _p],
     "ovd_video_to_uint8": [_p, _p, _l, _l, _i, _l, _f, _f, _p],
+    "ovd_resid_layernorm_modulate": [_p, _l, _p, _l, _p, _p, _p, _p, _p, _p, _l, _i, _p, _i, _i, _f, _i, _p],
     "ovd_quant_rows_fp8": [_p, _l, _p, _l, _p, _i, _i, _p],
     "ovd_layernorm_modulate_fp8": [_p, _l, _p, _p, _p, _p, _p, _l, _p, _i, _i, _f, _i, _p],
     "ovd_gemm_fp8": [_p, _l, _p, _f, _p, _l, _p, _p, _p, _l, _p, _f, _i, _i, _i, _i, _p],
@@ -130,6 +131,29 @@ def layernorm_modulate(x, out, eps, shift=None, scale=None, weight=None, bias=No
         raise TypeError("layernorm: out must be bf16 or fp32")
     _call(name, _ptr(x, F32), ldx, _ptr(shift, F32, True), _ptr(scale, F32, True), _ptr(weight, BF16, True),
           _ptr(bias, BF16, True), _ptr(out), ldo, M, C, float(eps), int(round_norm), _stream())
+    return out
+
+
+def resid_layernorm_modulate(x, res, out, eps, res_gate=None, shift=None, scale=None, weight=None, bias=None,
+                             round_norm=False, row_scale=None):
+    """x += res * res_gate (in place), then LayerNorm (+ affine) (+ modulation) of the updated x into
+    out (bf16, fp32, or uint8 = e4m3 with row_scale)."""
+    M, C, ldx = _rows(x)
+    Mr, Cr, ldr = _rows(res)
+    Mo, Co, ldo = _rows(out)
+    if (Mo, Co) != (M, C) or (Mr, Cr) != (M, C):
+        raise ValueError("layernorm: shape mismatch")
+    for v in (shift, scale, res_gate):
+        if v is not None and (v.numel() != C or not v.is_contiguous()):
+            raise ValueError("layernorm: shift/scale/gate must be contiguous rows of length C")
+    kind = {BF16: 0, F32: 1, torch.uint8: 2}.get(out.dtype)
+    if kind is None:
+        raise TypeError("layernorm: out must be bf16, fp32 or uint8 (e4m3)")
+    if kind == 2 and (row_scale is None or row_scale.numel() != M):
+        raise ValueError("layernorm: e4m3 output needs row_scale[M]")
+    _call("ovd_resid_layernorm_modulate", _ptr(x, F32), ldx, _ptr(res, BF16), ldr, _ptr(res_gate, F32, True),
+          _ptr(shift, F32, True), _ptr(scale, F32, True), _ptr(weight, BF16, True), _ptr(bias, BF16, True), _ptr(out),
+          ldo, kind, _ptr(row_scale, F32, True), M, C, float(eps), int(round_norm), _stream())
     return out
 
 

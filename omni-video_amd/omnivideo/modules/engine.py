@@ -177,6 +177,7 @@ class DiTEngine:
         self.x = e(nb, S, C, dt=F32)
         self.qkv = e(nb, S, 3 * C)
         self.att = e(nb, S, C)
+        self.res = e(M, C)             # output of a sub-layer's last Linear until the next norm adds it to x
         if self.precision == "fp8":
             self.h8, self.h_scale = e(M, C, dt=torch.uint8), e(M, dt=F32)
             self.att8, self.att_scale = e(M, C, dt=torch.uint8), e(M, dt=F32)
@@ -260,6 +261,28 @@ class DiTEngine:
         self.comm.all_to_all(self.sp_orecv, self.sp_osend)
         self.att.view(nb, S, sp, Cs).copy_(self.sp_orecv.permute(1, 2, 0, 3))
 
+    # ------------------------------------------------------------------ sub-layer pieces
+    def _norm(self, x2, pending, **kw):
+        """LayerNorm (+ affine / modulation) of the residual stream into the GEMM input buffer (bf16
+        `h`, or e4m3 `h8` + row scales), after adding the pending residual update (y, gate) to x."""
+        fp8 = self.precision == "fp8"
+        if pending is not None:
+            H.resid_layernorm_modulate(x2, pending[0], self.h8 if fp8 else self.h, self.eps, res_gate=pending[1],
+                                       row_scale=self.h_scale if fp8 else None, **kw)
+        elif fp8:
+            H.layernorm_modulate_fp8(x2, self.h8, self.h_scale, self.eps, **kw)
+        else:
+            H.layernorm_modulate(x2, self.h, self.eps, **kw)
+
+    def _linear_from_attention(self, att2, L, name):
+        """self.res = Linear(attention output) in bf16 (the o projections, model.py:152, 177)."""
+        if self.precision == "fp8":
+            H.quant_rows_fp8(att2, self.att8, self.att_scale)
+            H.gemm_fp8(self.att8, L["w8_" + name], L["s_" + name], self.res, L["b_" + name], H.EPI_BF16,
+                       a_scale=self.att_scale)
+        else:
+            H.gemm(att2, L["w_" + name], self.res, L["b_" + name], H.EPI_BF16)
+
     # ------------------------------------------------------------------ forward
     def forward(self, lat, timesteps, ctx, out, step=0, step_ptr=None):
         """lat [Cin,T,H,W] (bf16 or fp32, rounded to bf16 on entry as the reference's bf16
@@ -293,15 +316,16 @@ class DiTEngine:
         att4 = self.att.unflatten(2, (N, D))
         att2 = self.att.view(M, C)
         fp8 = self.precision == "fp8"
+        # The residual updates x = x + y * e (model.py:245-246, 250, 253-254) are applied by the norm
+        # kernel that follows each of them (resid_layernorm_modulate): `pending` carries (y, e).
+        pending = None
         for l, L in enumerate(self.layers):
             mod = self.mod[l]
             # self-attention (model.py:242-246)
+            self._norm(x2, pending, shift=mod[0], scale=mod[1], round_norm=(l == 0))
             if fp8:
-                H.layernorm_modulate_fp8(x2, self.h8, self.h_scale, self.eps, shift=mod[0], scale=mod[1],
-                                         round_norm=(l == 0))
                 H.gemm_fp8(self.h8, L["w8_qkv"], L["s_qkv"], qkv2, L["b_qkv"], H.EPI_BF16, a_scale=self.h_scale)
             else:
-                H.layernorm_modulate(x2, self.h, self.eps, shift=mod[0], scale=mod[1], round_norm=(l == 0))
                 H.gemm(self.h, L["w_qkv"], qkv2, L["b_qkv"], H.EPI_BF16)
             for sl, nw in ((slice(0, C), L["nq"]), (slice(C, 2 * C), L["nk"])):
                 v_ = qkv2[:, sl]
@@ -311,41 +335,39 @@ class DiTEngine:
                 self._self_attention_sp()
             else:
                 self._self_attention(q4, k4, v4, att4)
-            if fp8:
-                H.quant_rows_fp8(att2, self.att8, self.att_scale)
-                H.gemm_fp8(self.att8, L["w8_o"], L["s_o"], x2, L["b_o"], H.EPI_RESID, a_scale=self.att_scale,
-                           gate=mod[2])
-            else:
-                H.gemm(att2, L["w_o"], x2, L["b_o"], H.EPI_RESID, gate=mod[2])
+            self._linear_from_attention(att2, L, "o")
+            pending = (self.res, mod[2])
             # cross-attention (model.py:250): local query rows against the replicated context K/V
+            self._norm(x2, pending, weight=L["n3w"], bias=L["n3b"])
             qc = qkv2[:, :C]
             if fp8:
-                H.layernorm_modulate_fp8(x2, self.h8, self.h_scale, self.eps, weight=L["n3w"], bias=L["n3b"])
                 H.gemm_fp8(self.h8, L["w8_cq"], L["s_cq"], qc, L["b_cq"], H.EPI_BF16, a_scale=self.h_scale)
             else:
-                H.layernorm_modulate(x2, self.h, self.eps, weight=L["n3w"], bias=L["n3b"])
                 H.gemm(self.h, L["w_cq"], qc, L["b_cq"], H.EPI_BF16)
             H.rmsnorm_rope(qc, L["cnq"], qc, D, self.eps)
             kvl = ctx.kv[l]
             H.flash_attn(q4, kvl[:, :, :C].unflatten(2, (N, D)), kvl[:, :, C:].unflatten(2, (N, D)), att4,
                          k_len=ctx.k_len, last_key_copies=ctx.last_key_copies)
+            self._linear_from_attention(att2, L, "co")
+            pending = (self.res, None)
             # feed-forward (model.py:251-254)
+            self._norm(x2, pending, shift=mod[3], scale=mod[4])
             if fp8:
-                H.quant_rows_fp8(att2, self.att8, self.att_scale)
-                H.gemm_fp8(self.att8, L["w8_co"], L["s_co"], x2, L["b_co"], H.EPI_RESID, a_scale=self.att_scale)
-                H.layernorm_modulate_fp8(x2, self.h8, self.h_scale, self.eps, shift=mod[3], scale=mod[4])
                 H.gemm_fp8(self.h8, L["w8_f0"], L["s_f0"], self.ffn8, L["b_f0"], H.EPI_FP8_GELU, a_scale=self.h_scale,
                            out_scale=self.ffn_act_scale)
-                H.gemm_fp8(self.ffn8, L["w8_f2"], L["s_f2"], x2, L["b_f2"], H.EPI_RESID,
-                           a_scale_all=self.ffn_act_scale, gate=mod[5])
+                H.gemm_fp8(self.ffn8, L["w8_f2"], L["s_f2"], self.res, L["b_f2"], H.EPI_BF16,
+                           a_scale_all=self.ffn_act_scale)
             else:
-                H.gemm(att2, L["w_co"], x2, L["b_co"], H.EPI_RESID)
-                H.layernorm_modulate(x2, self.h, self.eps, shift=mod[3], scale=mod[4])
                 H.gemm(self.h, L["w_f0"], self.ffn, L["b_f0"], H.EPI_BF16_GELU)
-                H.gemm(self.ffn, L["w_f2"], x2, L["b_f2"], H.EPI_RESID, gate=mod[5])
+                H.gemm(self.ffn, L["w_f2"], self.res, L["b_f2"], H.EPI_BF16)
+            pending = (self.res, mod[5])
         # head + unpatchify (model.py:520-524)
         H.head_modulation(self.head_mod, self.e_vec, self.hmod)
-        H.layernorm_modulate(x2, self.y, self.eps, shift=self.hmod[0], scale=self.hmod[1])
+        if pending is None:
+            H.layernorm_modulate(x2, self.y, self.eps, shift=self.hmod[0], scale=self.hmod[1])
+        else:
+            H.resid_layernorm_modulate(x2, pending[0], self.y, self.eps, res_gate=pending[1], shift=self.hmod[0],
+                                       scale=self.hmod[1])
         if self.sp > 1:
             out.zero_()
         for b in range(nb):

@@ -314,3 +314,35 @@ def test_attention_tail_balancing_equals_plain_call(H, B, N, L, k_len, copies):
     assert torch.equal(small, plain)
     # shapes that do not profit report 0
     assert H.flash_attn_workspace_bytes(1, 1024, 2, 1024) == 0 and H.flash_attn_workspace_bytes(2, 75600, 40, 75600) == 0
+
+
+@pytest.mark.parametrize("M,C", [(515, 1536), (100, 5120), (64, 256)])
+def test_resid_layernorm_equals_gemm_residual_epilogue_then_layernorm(H, M, C):
+    """x += y * gate inside the norm kernel == the GEMM's residual epilogue followed by the norm, bit
+    for bit, for every output kind."""
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    K = 256
+    a = (torch.randn(M, K, device="cuda", generator=g)).to(BF16)
+    w = (torch.randn(C, K, device="cuda", generator=g) / 16).to(BF16)
+    bias = (torch.randn(C, device="cuda", generator=g) * 0.1).to(BF16)
+    x0 = torch.randn(M, C, device="cuda", generator=g)
+    gate, shift, scale = (torch.randn(C, device="cuda", generator=g) * 0.5 for _ in range(3))
+    for use_gate in (True, False):
+        gt = gate if use_gate else None
+        x_ref = x0.clone()
+        H.gemm(a, w, x_ref, bias, H.EPI_RESID, gate=gt)
+        y = torch.empty(M, C, device="cuda", dtype=BF16)
+        H.gemm(a, w, y, bias, H.EPI_BF16)
+        for dt in (BF16, F32, torch.uint8):
+            x = x0.clone()
+            out = torch.empty(M, C, device="cuda", dtype=dt)
+            ref = torch.empty(M, C, device="cuda", dtype=dt)
+            if dt == torch.uint8:
+                rs, rs_ref = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+                H.layernorm_modulate_fp8(x_ref, ref, rs_ref, 1e-6, shift=shift, scale=scale)
+                H.resid_layernorm_modulate(x, y, out, 1e-6, res_gate=gt, shift=shift, scale=scale, row_scale=rs)
+                assert torch.equal(rs, rs_ref)
+            else:
+                H.layernorm_modulate(x_ref, ref, 1e-6, shift=shift, scale=scale)
+                H.resid_layernorm_modulate(x, y, out, 1e-6, res_gate=gt, shift=shift, scale=scale)
+            assert torch.equal(x, x_ref) and torch.equal(out, ref)

@@ -165,6 +165,21 @@ if __name__ == "__main__":
         gemm8(M, 8960, 1536, 4)
         gemm8(M, 1536, 8960, 3)
         gemm8(8192, 8192, 8192, 0)
+    if "gemmepi" in args.what:      # what each epilogue costs on the K = 1536 shapes
+        for epi in (0, 1, 2, 3):
+            gemm(40560, 1536, 1536, epi)
+        gemm(40560, 4608, 1536, 0)
+        gemm(40560, 4608, 1536, 2)
+    if "lnres" in args.what:        # LayerNorm-modulate with and without the fused residual update
+        M, C = 40560, 1536
+        x = torch.randn(M, C, device="cuda")
+        y = torch.randn(M, C, device="cuda").to(BF16)
+        sh, sc, gt = (torch.randn(C, device="cuda") * 0.1 for _ in range(3))
+        h = torch.empty(M, C, device="cuda", dtype=BF16)
+        ms = timeit(lambda: H.layernorm_modulate(x, h, 1e-6, shift=sh, scale=sc))
+        print(f"ln_mod {M}x{C}: {ms * 1e3:.1f} us  {M * C * 6 / ms / 1e9:.2f} TB/s")
+        ms = timeit(lambda: H.resid_layernorm_modulate(x, y, h, 1e-6, res_gate=gt, shift=sh, scale=sc))
+        print(f"resid ln_mod {M}x{C}: {ms * 1e3:.1f} us  {M * C * 12 / ms / 1e9:.2f} TB/s")
     if "gemm" in args.what:
         M = 40560
         gemm(M, 4608, 1536, 0)      # fused QKV
