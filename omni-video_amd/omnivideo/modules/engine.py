@@ -88,6 +88,34 @@ class TorchGroupComm:
     def all_reduce_sum(self, t):
         dist.all_reduce(t, group=self.group)
 
+    # --- the two exchanges of the row-sharded VAE decode (vae2_1.WanVAE_.decode with comm=...)
+    def exchange_rows(self, up, down):
+        """Sends `up` to rank - 1 and `down` to rank + 1; returns (row received from rank - 1, row
+        received from rank + 1), None where there is no such neighbour."""
+        ops, from_up, from_down = [], None, None
+        g = self.group
+        peer = (lambda r: dist.get_global_rank(g, r)) if g is not None else (lambda r: r)
+        if self.rank > 0:
+            from_up = torch.empty_like(up)
+            ops += [dist.P2POp(dist.isend, up, peer(self.rank - 1), group=g),
+                    dist.P2POp(dist.irecv, from_up, peer(self.rank - 1), group=g)]
+        if self.rank < self.size - 1:
+            from_down = torch.empty_like(down)
+            ops += [dist.P2POp(dist.isend, down, peer(self.rank + 1), group=g),
+                    dist.P2POp(dist.irecv, from_down, peer(self.rank + 1), group=g)]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return from_up, from_down
+
+    def all_gather_rows(self, x, rows):
+        """x [T, rows[rank], ...] on every rank -> [T, sum(rows), ...] on every rank."""
+        mx = max(rows)
+        pad = x.new_zeros((x.shape[0], mx) + tuple(x.shape[2:]))
+        pad[:, :x.shape[1]] = x
+        parts = [torch.empty_like(pad) for _ in range(self.size)]
+        dist.all_gather(parts, pad, group=self.group)
+        return torch.cat([p[:, :n] for p, n in zip(parts, rows)], dim=1)
+
 
 FP8_LINEARS = ("qkv", "o", "cq", "co", "f0", "f2")
 

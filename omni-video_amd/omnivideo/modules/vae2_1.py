@@ -156,6 +156,50 @@ class _Ctx:
             self.r2, self.r1 = self.r1, (rn[-1] if rn is not None else None)
 
 
+def shard_rows(total, parts):
+    """Row counts of `total` rows split over `parts` ranks, as even as possible, larger first."""
+    q, r = divmod(total, parts)
+    return [q + (i < r) for i in range(parts)]
+
+
+class _Shard:
+    """Row-sharded execution of the decoder over the ranks of a sequence-parallel group (the
+    reference decodes on the group's first rank only while the others idle,
+    x2x_gen_unified.py:512-524).  Rank r owns a horizontal strip of every activation, held with
+    one extra row above and below ([T, rows + 2, W, C]).  Before a convolution with spatial extent
+    the two extra rows are refreshed: the neighbour's adjacent row, or zeros at the image border -
+    exactly what the unsharded convolution sees there (its zero padding).  Everything without
+    spatial extent (1x1x1 and temporal convolutions, norms, residual adds) runs on the strip as
+    is; the values in the extra rows between refreshes are never read by a valid output."""
+
+    def __init__(self, comm, rows):
+        self.comm, self.rows = comm, list(rows)
+
+    def refresh(self, x):
+        up, down = self.comm.exchange_rows(x[:, 1].contiguous(), x[:, -2].contiguous())
+        if up is None:
+            x[:, 0].zero_()
+        else:
+            x[:, 0].copy_(up)
+        if down is None:
+            x[:, -1].zero_()
+        else:
+            x[:, -1].copy_(down)
+
+    def gather(self, x, scale=1):
+        """strip with its extra rows -> the full-height tensor (on every rank)."""
+        return self.comm.all_gather_rows(x[:, 1:-1].contiguous(), [n * scale for n in self.rows])
+
+    def strip(self, full, scale=1):
+        """full-height tensor -> this rank's strip with (stale) extra rows."""
+        r0 = sum(self.rows[:self.comm.rank]) * scale
+        n = self.rows[self.comm.rank] * scale
+        out = full.new_zeros((full.shape[0], n + 2) + tuple(full.shape[2:]))
+        lo, hi = max(r0 - 1, 0), min(r0 + n + 1, full.shape[1])
+        out[:, lo - (r0 - 1):lo - (r0 - 1) + hi - lo] = full[:, lo:hi]
+        return out
+
+
 class _Runner:
     """Executes the encoder / decoder chunk by chunk on channels-last tensors."""
 
@@ -163,6 +207,7 @@ class _Runner:
         self.m = model
         self.ctx = {}
         self._w = {}
+        self.shard = None           # a _Shard while a row-sharded decode is running
 
     def reset(self):
         self.ctx = {}
@@ -190,6 +235,8 @@ class _Runner:
         """Causal conv with optional fused RMS-norm(+SiLU) on the input.  `name` keys the
         temporal context; None = stateless (1x1x1 convs, per-frame 2D convs)."""
         w, b, k = self.weight(conv)
+        if self.shard is not None and k[1] > 1:
+            self.shard.refresh(x)
         rn = H.vae_voxel_rnorm(x) if norm is not None else None
         gamma = norm.gamma.detach().reshape(-1).to(F32).contiguous() if norm is not None else None
         c = self.ctx.setdefault(name, _Ctx()) if name is not None else None
@@ -213,6 +260,12 @@ class _Runner:
     def attn_block(self, x, blk):
         """reference AttentionBlock.forward (vae2_1.py:239-261): per frame, one head of
         width C over the h*w positions; q/k/v are 1x1 convs of the RMS-normed input."""
+        if self.shard is not None:      # attention spans the whole frame: gather, compute, keep the own strip
+            sh, self.shard = self.shard, None
+            try:
+                return sh.strip(self.attn_block(sh.gather(x), blk))
+            finally:
+                self.shard = sh
         T, Hh, Ww, C = x.shape
         L = Hh * Ww
         if L % 4:
@@ -253,6 +306,10 @@ class _Runner:
                 c.push(x, None)
                 x = y
         w, b, k = self.weight(rs.resample[1])
+        if self.shard is not None:
+            # [rows + 2] -> 2 rows + 4: the outermost row on each side is dropped, leaving one extra row
+            self.shard.refresh(x)
+            return H.vae_conv3d(x, w, b, k, pad_hw=1, upsample2=True)[:, 1:-1].contiguous()
         return H.vae_conv3d(x, w, b, k, pad_hw=1, upsample2=True)
 
     def downsample(self, x, rs, name):
@@ -348,11 +405,14 @@ class WanVAE_(nn.Module):
         run.reset()
         return z[None]
 
-    def decode(self, z, scale, as_frames=False):
+    def decode(self, z, scale, as_frames=False, comm=None):
         """z [1,z,T,h,w] -> video [1,3,4T-3,8h,8w] (reference vae2_1.py:543-567).  With
         `as_frames` the decoder's channels-last output is converted straight to the uint8
         [4T-3,8h,8w,3] frames that the reference's cache_video hands to its video writer
-        (utils/utils.py:175-182), without materialising the planar fp32 video."""
+        (utils/utils.py:175-182), without materialising the planar fp32 video.
+        comm: a communicator of `size` ranks (rank, size, exchange_rows, all_gather_rows; e.g.
+        engine.TorchGroupComm over the sequence-parallel group): every rank passes the same z,
+        decodes a horizontal strip of the video (see _Shard) and receives the full result."""
         dev = self.conv1.weight.device
         if z.shape[0] != 1:
             raise NotImplementedError("batch of one, as the pipeline calls it")
@@ -361,8 +421,18 @@ class WanVAE_(nn.Module):
         mean, inv_std = self._scale_vectors(scale, self.z_dim, dev)
         zc = H.vae_to_channels_last(z[0].to(dev, F32).contiguous(), mul=(1.0 / inv_std).contiguous(), post=mean)
         x = run.conv(zc, self.conv2)
-        outs = [run.decoder_chunk(x[i:i + 1]) for i in range(x.shape[0])]
-        out = torch.cat(outs, dim=0)
+        if comm is not None and comm.size > 1:
+            if x.shape[1] < comm.size:
+                raise ValueError(f"cannot shard {x.shape[1]} latent rows over {comm.size} ranks")
+            run.shard = _Shard(comm, shard_rows(x.shape[1], comm.size))
+            x = run.shard.strip(x)
+        try:
+            outs = [run.decoder_chunk(x[i:i + 1]) for i in range(x.shape[0])]
+            out = torch.cat(outs, dim=0)
+            if run.shard is not None:
+                out = run.shard.gather(out, scale=2 ** (len(self.dim_mult) - 1))
+        finally:
+            run.shard = None
         run.reset()
         if as_frames:
             return H.video_to_uint8(out, channels_last=True)
@@ -401,11 +471,12 @@ class Wan2_1_VAE:
         """videos: list of [3,T,H,W] -> list of fp32 [z,T',h,w]."""
         return [self.model.encode(u.unsqueeze(0), self.scale).float().squeeze(0) for u in videos]
 
-    def decode(self, zs):
-        """zs: list of [z,T,h,w] -> list of fp32 [3,4T-3,8h,8w] clamped to [-1,1]."""
-        return [self.model.decode(u.unsqueeze(0), self.scale).float().clamp_(-1, 1).squeeze(0) for u in zs]
+    def decode(self, zs, comm=None):
+        """zs: list of [z,T,h,w] -> list of fp32 [3,4T-3,8h,8w] clamped to [-1,1].  comm (extension):
+        decode row-sharded over the ranks of a communicator, see WanVAE_.decode."""
+        return [self.model.decode(u.unsqueeze(0), self.scale, comm=comm).float().clamp_(-1, 1).squeeze(0) for u in zs]
 
-    def decode_frames(self, zs):
+    def decode_frames(self, zs, comm=None):
         """zs: list of [z,T,h,w] -> list of uint8 [4T-3,8h,8w,3] frames: decode() followed by the
         tensor half of cache_video (reference utils/utils.py:175-182) in one pass."""
-        return [self.model.decode(u.unsqueeze(0), self.scale, as_frames=True) for u in zs]
+        return [self.model.decode(u.unsqueeze(0), self.scale, as_frames=True, comm=comm) for u in zs]

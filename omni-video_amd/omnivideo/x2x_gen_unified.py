@@ -300,7 +300,13 @@ class OmniVideoX2XUnified:
             is_decode_rank = (self.sp_rank == 0) if self.use_usp else (self.rank == 0)
             if return_latents or self.vae is None:
                 return lat if is_decode_rank else None
-            videos = self.vae.decode([lat]) if is_decode_rank else [None]
+            if self.sp_comm is not None and lat.shape[2] >= self.sp_comm.size:
+                # the reference decodes on the first rank of the group while the others wait
+                # (x2x_gen_unified.py:512-524); here every rank decodes a strip of rows and all of
+                # them receive the video, which only the first one returns
+                videos = self.vae.decode([lat], comm=self.sp_comm)
+            else:
+                videos = self.vae.decode([lat]) if is_decode_rank else [None]
         if dist.is_initialized():
             dist.barrier()
         return videos[0] if is_decode_rank else None

@@ -42,26 +42,63 @@ def main():
     C, NH, grid, S = cfg["dim"], cfg["num_heads"], (3, 4, 6), 80
     x = syn.randn("probe.x", (1, S, C), 3)[0]
     pre = "wan_model.blocks.1.self_attn"
-    ref = O.self_attention(x, sd, pre, NH, cfg["eps"], O.rope_angles(C // NH, grid), 72, "fp32")
-    s = S // sp
-    xs = x[r * s:(r + 1) * s]
-    Dh = C // NH
-    q = O.rms_norm(O.linear(xs, sd, pre + ".q", "fp32"), sd[pre + ".norm_q.weight"], cfg["eps"], "fp32")
-    k = O.rms_norm(O.linear(xs, sd, pre + ".k", "fp32"), sd[pre + ".norm_k.weight"], cfg["eps"], "fp32")
-    v = O.linear(xs, sd, pre + ".v", "fp32")
-    ang = O.rope_angles(Dh, grid)                       # [72, D/2]; rows past it are not rotated
-    lo, hi = r * s, min((r + 1) * s, ang.shape[0])
-    a_loc = ang[lo:hi] if hi > lo else ang[:0]
-    q = O.rope_rotate(q.view(s, NH, Dh), a_loc)
-    k = O.rope_rotate(k.view(s, NH, Dh), a_loc)
-    qf = U.all_to_all(q[None], 2, 1, group)[0]
-    kf = U.all_to_all(k[None], 2, 1, group)[0]
-    vf = U.all_to_all(v.view(1, s, NH, Dh), 2, 1, group)[0]
-    of = O.attention(qf, kf, vf, k_len=72, flow="fp32")
-    o = U.all_to_all(of[None], 1, 2, group)[0]
-    out = O.linear(o.reshape(s, C), sd, pre + ".o", "fp32")
-    full_out = U.gather_forward(out[None], 1, group)[0]
-    torch.testing.assert_close(full_out, ref, rtol=1e-4, atol=1e-5)
+    if NH % sp == 0 and S % sp == 0:      # the head split needs sp | heads (reference ulysses.py:33-34)
+        ref = O.self_attention(x, sd, pre, NH, cfg["eps"], O.rope_angles(C // NH, grid), 72, "fp32")
+        s = S // sp
+        xs = x[r * s:(r + 1) * s]
+        Dh = C // NH
+        q = O.rms_norm(O.linear(xs, sd, pre + ".q", "fp32"), sd[pre + ".norm_q.weight"], cfg["eps"], "fp32")
+        k = O.rms_norm(O.linear(xs, sd, pre + ".k", "fp32"), sd[pre + ".norm_k.weight"], cfg["eps"], "fp32")
+        v = O.linear(xs, sd, pre + ".v", "fp32")
+        ang = O.rope_angles(Dh, grid)                       # [72, D/2]; rows past it are not rotated
+        lo, hi = r * s, min((r + 1) * s, ang.shape[0])
+        a_loc = ang[lo:hi] if hi > lo else ang[:0]
+        q = O.rope_rotate(q.view(s, NH, Dh), a_loc)
+        k = O.rope_rotate(k.view(s, NH, Dh), a_loc)
+        qf = U.all_to_all(q[None], 2, 1, group)[0]
+        kf = U.all_to_all(k[None], 2, 1, group)[0]
+        vf = U.all_to_all(v.view(1, s, NH, Dh), 2, 1, group)[0]
+        of = O.attention(qf, kf, vf, k_len=72, flow="fp32")
+        o = U.all_to_all(of[None], 1, 2, group)[0]
+        out = O.linear(o.reshape(s, C), sd, pre + ".o", "fp32")
+        full_out = U.gather_forward(out[None], 1, group)[0]
+        torch.testing.assert_close(full_out, ref, rtol=1e-4, atol=1e-5)
+
+    # row-sharded VAE decode: the communicator's neighbour exchange and row gather, and the strip
+    # arithmetic of vae2_1._Shard, on a CPU stand-in of the decoder's spatial pattern
+    # (3x3 conv -> nearest 2x upsample + 3x3 conv) with uneven strips
+    import torch.nn.functional as F
+    from omnivideo.modules.engine import TorchGroupComm
+    from omnivideo.modules.vae2_1 import _Shard, shard_rows
+    comm = TorchGroupComm(group)
+    assert (comm.rank, comm.size) == (r, sp)
+    up, down = comm.exchange_rows(torch.full((2, 3), float(r)), torch.full((2, 3), float(r) + 0.5))
+    assert (up is None) == (r == 0) and (down is None) == (r == sp - 1)
+    assert up is None or torch.equal(up, torch.full((2, 3), float(r - 1) + 0.5))
+    assert down is None or torch.equal(down, torch.full((2, 3), float(r + 1)))
+    T, Hh, Ww, Cc = 2, 3 * sp + 1, 5, 3
+    rows = shard_rows(Hh, sp)
+    assert sum(rows) == Hh and max(rows) - min(rows) <= 1
+    full = syn.randn("halo.x", (T, Hh, Ww, Cc), 2)
+    w1, w2 = syn.randn("halo.w1", (4, Cc, 3, 3), 2) * 0.3, syn.randn("halo.w2", (2, 4, 3, 3), 2) * 0.3
+
+    def conv(x, w):          # channels-last 3x3 convolution with zero padding
+        return F.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1).contiguous()
+
+    def up2(x):
+        return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+
+    want = conv(up2(conv(full, w1)), w2)
+    sh = _Shard(comm, rows)
+    xs = sh.strip(full)
+    assert xs.shape[1] == rows[r] + 2
+    sh.refresh(xs)
+    y = conv(xs, w1)
+    sh.refresh(y)
+    u = conv(up2(y), w2)[:, 1:-1].contiguous()
+    got = sh.gather(u, scale=2)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    assert torch.equal(sh.gather(xs), full)
 
     # data-parallel prompt sharding arithmetic (reference generate_omni_v2v.py:443-457,572-574)
     dp_world = world // sp

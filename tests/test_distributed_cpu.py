@@ -16,7 +16,7 @@ def launch(nproc, sp, port):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
 
 
-@pytest.mark.parametrize("nproc,sp,port", [(2, 2, 29621), (4, 2, 29622)])
+@pytest.mark.parametrize("nproc,sp,port", [(2, 2, 29621), (4, 2, 29622), (3, 3, 29623)])
 def test_sequence_parallel_collectives(nproc, sp, port):
     res = launch(nproc, sp, port)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
