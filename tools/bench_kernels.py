@@ -139,6 +139,8 @@ if __name__ == "__main__":
         attn(2, 20280, 20280, 12)
         attn(2, 20280, 20280, 12, balance=True)
         attn(2, 20280, 6144, 12)
+    if "attnbal" in args.what:      # the cfg2 self-attention launch alone (for counter passes)
+        attn(2, 20280, 20280, 12, balance=True)
     if "xattn" in args.what:
         attn(2, 20280, 512, 12)
         attn(2, 20280, 512, 12, strided_q=True)
