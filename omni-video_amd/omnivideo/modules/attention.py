@@ -12,13 +12,17 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
     """q [B,Lq,Nq,C1], k [B,Lk,Nk,C1], v [B,Lk,Nk,C2]; k_lens [B] masks the key tail.
     Returns [B,Lq,Nq,C2] in q's original dtype, computed in bf16 with fp32 accumulation.
     Built for what the DiT uses: C1 = C2 = 128, Nq = Nk, non-causal, no dropout, no
-    window, q_lens = None; anything else raises."""
+    window, q_lens = None or all equal to Lq; anything else raises."""
     if dtype != torch.bfloat16:
         raise NotImplementedError("flash_attention: only bf16 compute is built")
     if q.device.type != "cuda" or q.size(-1) > 256:
         raise AssertionError("flash_attention needs a HIP device tensor with head_dim <= 256")
-    if causal or dropout_p != 0. or tuple(window_size) != (-1, -1) or q_lens is not None:
-        raise NotImplementedError("flash_attention: causal / dropout / window / q_lens are not built")
+    if causal or dropout_p != 0. or tuple(window_size) != (-1, -1):
+        raise NotImplementedError("flash_attention: causal / dropout / window are not built")
+    if q_lens is not None and any(int(n) != q.size(1) for n in q_lens.tolist()):
+        # the reference unflattens the packed output back to [B, Lq] (attention.py:133), which only
+        # works when every q_len equals Lq
+        raise NotImplementedError("flash_attention: q_lens shorter than Lq are not built")
     if q.shape[2] != k.shape[2] or q.shape[3] != 128 or v.shape[3] != 128:
         raise NotImplementedError("flash_attention: needs Nq == Nk and head_dim 128")
     out_dtype = q.dtype

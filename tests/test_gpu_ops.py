@@ -346,3 +346,25 @@ def test_resid_layernorm_equals_gemm_residual_epilogue_then_layernorm(H, M, C):
                 H.layernorm_modulate(x_ref, ref, 1e-6, shift=shift, scale=scale)
                 H.resid_layernorm_modulate(x, y, out, 1e-6, res_gate=gt, shift=shift, scale=scale)
             assert torch.equal(x, x_ref) and torch.equal(out, ref)
+
+
+def test_reference_signature_flash_attention_lens_scale_dtype():
+    """omnivideo.modules.flash_attention (reference attention.py:24-133): per-sample k_lens, full
+    q_lens, q_scale, softmax_scale, and the result back in q's dtype."""
+    from omnivideo.modules import flash_attention
+    B, Lq, Lk, N, D = 2, 70, 90, 2, 128
+    q = rb(syn.randn("fa2.q", (B, Lq, N, D), 6))
+    k = rb(syn.randn("fa2.k", (B, Lk, N, D), 6))
+    v = rb(syn.randn("fa2.v", (B, Lk, N, D), 6))
+    k_lens = torch.tensor([90, 37])
+    out = flash_attention(dev(q), dev(k), dev(v), q_lens=torch.tensor([Lq, Lq]), k_lens=k_lens, softmax_scale=0.07,
+                          q_scale=0.5)
+    assert out.dtype == F32 and tuple(out.shape) == (B, Lq, N, D)
+    for b in range(B):
+        # the oracle scales by 1/sqrt(D): fold the ratio to the requested scale into q (fp32 flow: no rounding)
+        ref = O.attention(rb(q[b] * 0.5) * (0.07 * D ** 0.5), k[b], v[b], k_len=int(k_lens[b]), flow="fp32")
+        assert_bf16_close(out[b], ref, ulps=3.0, atol=8e-3)
+    with pytest.raises(NotImplementedError):
+        flash_attention(dev(q), dev(k), dev(v), q_lens=torch.tensor([Lq, Lq - 1]))
+    with pytest.raises(NotImplementedError):
+        flash_attention(dev(q), dev(k), dev(v), causal=True)
