@@ -391,9 +391,13 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
         return;
     }
     const float inv = 1.0f / half_sum(l_run);
-    const int qr = q0 + l31;
-    if (qr < Lq) {
-        bf16_t* op = O + b * o_bs + (long)qr * o_ld + (long)head * HD + 4 * hi;
+    // Output through LDS (the K/V buffers are free after the last step's barrier; 8 KiB per wave):
+    // the accumulators hold 4 consecutive d of one query row per register group, which stored
+    // directly are 16-byte fragments per row.  Written as [32 rows][256 B] with 16-byte chunk c of
+    // row r at c ^ (r & 15) (two lanes per bank: the minimum for 512 B), read back a quarter row per
+    // lane so that every store instruction covers four rows of two full 128-byte lines.
+    {
+        char* ep = smem + wave * 8192;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -401,8 +405,16 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
                 uint2 w;
                 w.x = pack_bf2(o_acc[db][4 * g4 + 0] * inv, o_acc[db][4 * g4 + 1] * inv);
                 w.y = pack_bf2(o_acc[db][4 * g4 + 2] * inv, o_acc[db][4 * g4 + 3] * inv);
-                *reinterpret_cast<uint2*>(op + db * 32 + 8 * g4) = w;
+                *reinterpret_cast<uint2*>(ep + l31 * 256 + (((db * 4 + g4) ^ (l31 & 15)) << 4) + hi * 8) = w;
             }
+        const int rr = lane >> 4, cc = lane & 15;
+        bf16_t* ob = O + b * o_bs + (long)head * HD + cc * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = i * 4 + rr;
+            const uint4 w = *reinterpret_cast<const uint4*>(ep + r * 256 + ((cc ^ (r & 15)) << 4));
+            if (q0 + r < Lq) *reinterpret_cast<uint4*>(ob + (long)(q0 + r) * o_ld) = w;
+        }
     }
 }
 
@@ -493,8 +505,9 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
     OVD_REQUIRE(D == HD, "attention: head_dim %d not supported (only 128)", D);
     OVD_REQUIRE(B > 0 && N > 0 && Lq > 0 && Lk > 0, "attention: empty problem B=%d N=%d Lq=%d Lk=%d", B, N, Lq, Lk);
     OVD_REQUIRE(k_len > 0 && k_len <= Lk, "attention: k_len=%d outside (0, Lk=%d]", k_len, Lk);
-    OVD_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && v_ld % 8 == 0 && o_ld % 4 == 0,
-                "attention: token strides must keep 16-byte alignment");
+    OVD_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && v_ld % 8 == 0 && o_ld % 8 == 0 && o_bs % 8 == 0 &&
+                    reinterpret_cast<uintptr_t>(out) % 16 == 0,
+                "attention: token strides and the output pointer must keep 16-byte alignment");
     OVD_REQUIRE(q_ld >= (long)N * D && k_ld >= (long)N * D && v_ld >= (long)N * D && o_ld >= (long)N * D,
                 "attention: token stride shorter than N*D");
     OVD_REQUIRE(softmax_scale > 0.f, "attention: softmax_scale must be positive");

@@ -50,14 +50,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), with tanh(u) = sign(u) (1 - 2 / (e^{2|u|} + 1))
-    // from one v_exp_f32 and one v_rcp_f32: absolute error of tanh ~1e-7, the same size as the
-    // rounding of (1 + tanh) in the fp32 formula itself.
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(u) * 2.8853900817779268f);
-    const float t = __builtin_copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f), u);
-    return 0.5f * x * (1.0f + t);
+    // 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), written as x / (1 + e^{-2u}) (the same
+    // function: 0.5 (1 + tanh u) is the logistic function of 2u): one v_exp_f32, one v_rcp_f32 and five
+    // multiply-adds.  e^{-2u} overflows to +inf for u << 0 and the quotient is then x * 0 = -0, the
+    // limit of the function; absolute error ~1e-7 |x|, the size of the fp32 roundings of the usual form.
+    const float c0 = 2.0f * 0.7978845608028654f * 1.4426950408889634f;      // 2 sqrt(2/pi) log2(e)
+    const float c1 = c0 * 0.044715f;
+    const float u2 = x * __builtin_fmaf(c1, x * x, c0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u2));
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

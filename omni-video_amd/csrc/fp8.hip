@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(512, 2)
 gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict__ a_scale, float a_scale_all,
                 const uint8_t* __restrict__ W, long ldw, const float* __restrict__ w_scale,
                 const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
-                float out_inv_scale, int M, int N, int K, int tiles_m, int tiles_n, int GM) {
+                float out_inv_scale, int M, int N, int K, int tiles_m, int tiles_n, int GM, int wide_store) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -286,11 +286,15 @@ gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict
 
     // epilogue: acc[nt][mt] register 4g + j is out[m][n + j], m = row0 + wr*128 + mt*32 + (lane & 31),
     // n = col0 + wc*64 + nt*32 + 8g + 4*(lane >> 5)
+    constexpr bool NARROW_OUT = EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_FP8_GELU;
+    constexpr int OB = EPI == EPI_FP8_GELU ? 1 : 2;            // bytes per output element on the staged path
+    char* ep = smem + wave * 16384;
+    const bool staged = NARROW_OUT && wide_store;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = row0 + wr * 128 + mt * 32 + fr;
-        if (m >= M) continue;
-        const float sa_m = (a_scale ? a_scale[m] : 1.f) * a_scale_all;
+        if (!staged && m >= M) continue;
+        const float sa_m = (a_scale ? a_scale[min(m, M - 1)] : 1.f) * a_scale_all;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -314,12 +318,22 @@ gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict
                     uint2 o;
                     o.x = pack_bf2(y[0], y[1]);
                     o.y = pack_bf2(y[2], y[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)m * ldo + n) = o;
+                    if (staged) {      // rows of 128 B, 16-byte chunk c at c ^ ((r >> 1) & 7), as in gemm256.hip
+                        const int r = mt * 32 + fr, c = nt * 4 + g;
+                        *reinterpret_cast<uint2*>(ep + r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + fh * 8) = o;
+                    } else {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)m * ldo + n) = o;
+                    }
                 } else if (EPI == EPI_FP8_GELU) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) y[j] = round_bf(gelu_tanh_f(round_bf(y[j]))) * out_inv_scale;
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + (long)m * ldo + n) =
-                        pack_fp8x4(y[0], y[1], y[2], y[3]);
+                    const uint32_t o = pack_fp8x4(y[0], y[1], y[2], y[3]);
+                    if (staged) {      // rows of 64 B, chunk c at c ^ ((r >> 2) & 3)
+                        const int r = mt * 32 + fr, c = nt * 2 + (g >> 1);
+                        *reinterpret_cast<uint32_t*>(ep + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + (g & 1) * 8 + fh * 4) = o;
+                    } else {
+                        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + (long)m * ldo + n) = o;
+                    }
                 } else if (EPI == EPI_F32) {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)m * ldo + n) =
                         make_float4(round_bf(y[0]), round_bf(y[1]), round_bf(y[2]), round_bf(y[3]));
@@ -338,6 +352,20 @@ gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict
                     *p = x;
                 }
             }
+    }
+    if (staged) {
+        // the wave's 128 x 64 tile back out of LDS, 16 B per lane: whole 128-byte lines (bf16) or
+        // 64-byte half lines (e4m3) per row
+        constexpr int ROWB = 64 * OB, CPR = ROWB / 16, RPI = 64 / CPR;     // row bytes, chunks per row, rows per pass
+        const int rr = lane / CPR, cc = lane % CPR;
+        char* ob = reinterpret_cast<char*>(out) + ((long)(row0 + wr * 128) * ldo + col0 + wc * 64) * OB + cc * 16;
+#pragma unroll
+        for (int i = 0; i < 128 / RPI; ++i) {
+            const int r = i * RPI + rr;
+            const int sw = OB == 2 ? ((r >> 1) & 7) : ((r >> 2) & 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(ep + r * ROWB + ((cc ^ sw) << 4));
+            if (row0 + wr * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)r * ldo * OB) = v;
+        }
     }
 }
 
@@ -405,6 +433,9 @@ int ovd_impl_gemm_fp8(const uint8_t* A, long lda, const float* a_scale, float a_
     dim3 grid(tiles_m * tiles_n), blk(512);
     const size_t lds = NSTAGE * STAGE;
     const float out_inv = 1.f / out_scale;
+    // 16-byte output stores (bf16 and e4m3 epilogues) need 16-byte aligned rows
+    const long row_bytes = ldo * (epilogue == EPI_FP8_GELU ? 1 : 2);
+    const int wide = (row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
 #define GEMM_CASE(E)                                                                                      \
     case E: {                                                                                             \
         static bool attr_set = false;                                                                     \
@@ -415,7 +446,7 @@ int ovd_impl_gemm_fp8(const uint8_t* A, long lda, const float* a_scale, float a_
             attr_set = true;                                                                              \
         }                                                                                                 \
         hipLaunchKernelGGL((gemm_fp8_kernel<E>), grid, blk, lds, st, A, lda, a_scale, a_scale_all, W, ldw, \
-                           w_scale, bias, out, ldo, gate, out_inv, M, N, K, tiles_m, tiles_n, 4);         \
+                           w_scale, bias, out, ldo, gate, out_inv, M, N, K, tiles_m, tiles_n, 4, wide);   \
     } break;
     switch (epilogue) {
         GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) GEMM_CASE(EPI_FP8_GELU)

@@ -131,7 +131,7 @@ template <int EPI, int PHASES>
 __global__ void __launch_bounds__(512, 2)
 gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
                const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
-               int M, int N, int K, int tiles_m, int tiles_n, int GM) {
+               int M, int N, int K, int tiles_m, int tiles_n, int GM, int wide_store) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -210,31 +210,76 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
         if (wr == 0) __builtin_amdgcn_s_barrier();
     }
 
-    // epilogue: lane holds out[m][n..n+3], m = row0 + wr*128 + mt*16 + fr, n = col0 + wc*64 + nt*16 + fq*4
+    // epilogue: lane holds out[m][n..n+3], m = row0 + wr*128 + mt*16 + fr, n = col0 + wc*64 + nt*16 + fq*4.
+    // Rows outermost: the four stores of a lane for one row are the four 32-byte quarters of
+    // one 128-byte line (64 bf16 columns), issued back to back so that they merge on the way out.
     const int fr = lane & 15, fq = lane >> 4;
+    float bv[4][4], gv[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = col0 + wc * 64 + nt * 16 + fq * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bv[nt][j] = 0.f;
+            gv[nt][j] = 1.f;
+        }
         if (bias) {
             const uint2 bp = *reinterpret_cast<const uint2*>(bias + n);
-            bv[0] = bf2f(bp.x & 0xffff);
-            bv[1] = bf2f(bp.x >> 16);
-            bv[2] = bf2f(bp.y & 0xffff);
-            bv[3] = bf2f(bp.y >> 16);
+            bv[nt][0] = bf2f(bp.x & 0xffff);
+            bv[nt][1] = bf2f(bp.x >> 16);
+            bv[nt][2] = bf2f(bp.y & 0xffff);
+            bv[nt][3] = bf2f(bp.y >> 16);
         }
-        float gv[4] = {1.f, 1.f, 1.f, 1.f};
         if (EPI == EPI_RESID && gate) {
             const float4 g4 = *reinterpret_cast<const float4*>(gate + n);
-            gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+            gv[nt][0] = g4.x; gv[nt][1] = g4.y; gv[nt][2] = g4.z; gv[nt][3] = g4.w;
         }
+    }
+    if ((EPI == EPI_BF16 || EPI == EPI_BF16_GELU) && wide_store) {
+        // bf16 output through LDS: the ring is free (every wave is past the last barrier and every
+        // DMA has landed), each wave owns 16 KiB of it for its 128 x 64 tile = 128 rows of 128 B.
+        // Written in the accumulator layout (8 B per lane), read back 16 B per lane so that one
+        // store instruction covers 8 full 128-byte lines.  16-byte chunk c of row r sits at chunk
+        // c ^ ((r >> 1) & 7): the writes are 2 lanes per bank (the minimum for 512 B), the reads
+        // conflict-free.
+        char* ep = smem + wave * 16384;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int m = row0 + wr * 128 + mt * 16 + fr;
-            if (m >= M) continue;
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float y[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = acc[nt][mt][j] + bv[nt][j];
+                if (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(round_bf(y[j]));
+                }
+                uint2 o;
+                o.x = pack_bf2(y[0], y[1]);
+                o.y = pack_bf2(y[2], y[3]);
+                const int r = mt * 16 + fr, c = nt * 2 + (fq >> 1);
+                *reinterpret_cast<uint2*>(ep + r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + (fq & 1) * 8) = o;
+            }
+        const int rr = lane >> 3, cc = lane & 7;
+        bf16_t* ob = reinterpret_cast<bf16_t*>(out) + (long)(row0 + wr * 128) * ldo + col0 + wc * 64 + cc * 8;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = i * 8 + rr;
+            const uint4 v = *reinterpret_cast<const uint4*>(ep + r * 128 + ((cc ^ ((r >> 1) & 7)) << 4));
+            if (row0 + wr * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)r * ldo) = v;
+        }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = row0 + wr * 128 + mt * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = col0 + wc * 64 + nt * 16 + fq * 4;
             float y[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = acc[nt][mt][j] + bv[j];
+            for (int j = 0; j < 4; ++j) y[j] = acc[nt][mt][j] + bv[nt][j];
             if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
                 if (EPI == EPI_BF16_GELU) {
 #pragma unroll
@@ -250,10 +295,10 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
             } else {
                 float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)m * ldo + n);
                 float4 x = *p;
-                x.x += round_bf(y[0]) * gv[0];
-                x.y += round_bf(y[1]) * gv[1];
-                x.z += round_bf(y[2]) * gv[2];
-                x.w += round_bf(y[3]) * gv[3];
+                x.x += round_bf(y[0]) * gv[nt][0];
+                x.y += round_bf(y[1]) * gv[nt][1];
+                x.z += round_bf(y[2]) * gv[nt][2];
+                x.w += round_bf(y[3]) * gv[nt][3];
                 *p = x;
             }
         }
@@ -286,7 +331,7 @@ int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, 
             attr_set = true;                                                                              \
         }                                                                                                 \
         hipLaunchKernelGGL((gemm256_kernel<E, PH>), grid, blk, lds, st, A, lda, W, ldw, bias, out, ldo, gate, \
-                           M, N, K, tiles_m, tiles_n, gm);                                                \
+                           M, N, K, tiles_m, tiles_n, gm, wide);                                          \
     } break;
     // tile-rows per group of the tile walk (OVD_GEMM_GM overrides: tuning aid)
     static int gm = -1;
@@ -294,6 +339,8 @@ int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, 
         const char* e = getenv("OVD_GEMM_GM");
         gm = (e && atoi(e) > 0) ? atoi(e) : 4;
     }
+    // 16-byte output stores need 16-byte aligned rows
+    const int wide = (ldo % 8 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
     static int phases = -1;
     if (phases < 0) {
         const char* e = getenv("OVD_GEMM_PHASES");

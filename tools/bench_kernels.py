@@ -172,6 +172,11 @@ if __name__ == "__main__":
             gemm(40560, 1536, 1536, epi)
         gemm(40560, 4608, 1536, 0)
         gemm(40560, 4608, 1536, 2)
+    if "gemmk" in args.what:        # fixed cost per output tile: the same N, M at growing K
+        for K in (128, 256, 512, 1536):
+            gemm(40560, 8960, K, 1)
+        for K in (128, 256, 512, 1536):
+            gemm(40560, 8960, K, 0)
     if "lnres" in args.what:        # LayerNorm-modulate with and without the fused residual update
         M, C = 40560, 1536
         x = torch.randn(M, C, device="cuda")
