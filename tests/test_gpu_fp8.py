@@ -204,3 +204,33 @@ def test_full_width_block_fp8_vs_bf16_full_grid():
         del eng
     r = rel_l2(outs["fp8"], outs["bf16"])
     assert torch.isfinite(outs["fp8"]).all() and r < 6e-2, r
+
+
+def test_generate_fp8_linear_mode_tracks_bf16_trajectory():
+    """A guided 8-step sampling run through generate() with linear_precision="fp8" (graph replay
+    included) stays close to the bf16 run from the same noise: the quantisation error does not
+    build up over the steps."""
+    from omnivideo.configs import Config, t2v_1_3B
+    from omnivideo.utils import synthetic as syn
+    from omnivideo.x2x_gen_unified_1_3B import OmniVideoX2XUnified1_3B
+    cfg = syn.dit_config("tiny")
+    sd, sp = syn.make_unified_state_dict(cfg, 0), syn.make_special_tokens(cfg, 0)
+    text = syn.randn("in.text", (10, cfg["text_dim"]), 1).to(BF16)
+    text_null = syn.randn("in.text_null", (6, cfg["text_dim"]), 1).to(BF16)
+    visual = syn.randn("in.visual", (1, 16, 3, 8, 12), 1).cuda()
+    noise = syn.randn("gen.noise", (16, 3, 8, 12), 11).to(BF16)
+    lats = {}
+    for prec in ("bf16", "fp8"):
+        pipe = OmniVideoX2XUnified1_3B(Config(t2v_1_3B), None, vlm_in_dim=cfg["vlm_in_dim"],
+                                       use_visual_context_adapter=True,
+                                       visual_context_adapter_patch_size=cfg["visual_patch_size"],
+                                       max_context_len=cfg["text_len"], wan_config=dict(cfg), linear_precision=prec)
+        pipe.model.load_state_dict(sd, strict=True)
+        pipe.model.to(BF16)
+        pipe.special_tokens = {k: v.cuda().to(BF16) for k, v in sp.items()}
+        assert pipe.model.wan_model.linear_precision == prec
+        lats[prec] = pipe.generate("", precomputed_context=text, precomputed_context_null=text_null, visual_emb=visual,
+                                   size=(96, 64), frame_num=9, shift=5.0, sampling_steps=8, guide_scale=3.0, seed=1,
+                                   noise=noise, return_latents=True).float()
+    r = rel_l2(lats["fp8"], lats["bf16"])
+    assert torch.isfinite(lats["fp8"]).all() and 1e-4 < r < 8e-2, r
