@@ -141,6 +141,9 @@ if __name__ == "__main__":
         attn(2, 20280, 6144, 12)
     if "attnbal" in args.what:      # the cfg2 self-attention launch alone (for counter passes)
         attn(2, 20280, 20280, 12, balance=True)
+    if "xattn131" in args.what:     # cross-attention as the cfg2 model runs it: 131 keys read, fused K|V cache
+        for kl in (131, 512, 1024, 2048):
+            attn(2, 20280, 6144, 12, k_len=kl, strided_q=True, fused_kv=True)
     if "xattn" in args.what:
         attn(2, 20280, 512, 12)
         attn(2, 20280, 512, 12, strided_q=True)
