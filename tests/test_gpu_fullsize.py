@@ -184,3 +184,26 @@ def test_vae_decode_full_size_causality():
     head = vae.decode([z[:, :5].contiguous()])[0]
     assert tuple(head.shape) == (3, 17, 480, 832)
     assert torch.equal(head, full[:, :17])
+
+
+def test_full_depth_1p3b_forward_at_cpu_reference_case_shape():
+    """The whole 30-layer 1.3B DiT at the shape of the reference's CPU-runnable case (17 frames 256x256:
+    latent [16,5,32,32], 1 280 tokens, text_len 512) against the oracle forward in its bf16 flow - depth
+    is what the one-block test above cannot show (the oracle needs ~20 s of CPU for this)."""
+    from omnivideo.modules.unified_model import UnifiedWanWithMixedConditionModel
+    cfg = syn.dit_config("1.3B", text_len=512)
+    assert cfg["num_layers"] == 30
+    sd = syn.make_unified_state_dict(cfg, 0)
+    m = UnifiedWanWithMixedConditionModel(wan_config=dict(cfg), vlm_in_dim=cfg["vlm_in_dim"],
+                                          use_visual_context_adapter=True,
+                                          visual_context_adapter_patch_size=cfg["visual_patch_size"],
+                                          max_context_len=cfg["text_len"], eps=cfg["eps"], skip_init=True)
+    m.load_state_dict(sd, strict=True)
+    wm = m.to(BF16).cuda().eval().wan_model
+    lat = syn.randn("cfg1.lat", (16, 5, 32, 32), 1).to(BF16)
+    ctx = syn.randn("cfg1.text", (20, cfg["text_dim"]), 1).to(BF16)
+    out = wm([lat.cuda()], torch.tensor([875]), [ctx.cuda()], 1280)[0]
+    torch.cuda.synchronize()
+    ref = O.wan_forward(lat.float(), 875, ctx.float(), 1280, O.round_weights_bf16(sd), cfg, "bf16")
+    rel = float((out.cpu() - ref).norm() / ref.norm())
+    assert torch.isfinite(out).all() and rel < 3e-2, rel
