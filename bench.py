@@ -109,6 +109,47 @@ def cpu_baseline(cfg, wl, threads):
             "seconds_measured": dt}
 
 
+class _CpuStagedComm:
+    """Development aid for --rehearse-on-one-gpu: the communicator interface of
+    omnivideo.modules.engine.TorchGroupComm over gloo, staging device tensors through the host
+    (gloo's all-to-all and point-to-point paths take CPU tensors)."""
+
+    def __init__(self):
+        self.size, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def all_to_all(self, recv, send):
+        src = send.cpu().contiguous().view(torch.uint8).reshape(self.size, -1)       # bytes: any element type
+        r = torch.empty_like(src)
+        dist.all_to_all_single(r, src)
+        recv.copy_(r.view(recv.dtype).reshape(recv.shape))
+
+    def all_reduce_sum(self, t):
+        c = t.cpu()
+        dist.all_reduce(c)
+        t.copy_(c)
+
+    def exchange_rows(self, up, down):
+        ops, from_up, from_down = [], None, None
+        if self.rank > 0:
+            from_up = torch.empty(up.shape, dtype=up.dtype)
+            ops += [dist.P2POp(dist.isend, up.cpu(), self.rank - 1), dist.P2POp(dist.irecv, from_up, self.rank - 1)]
+        if self.rank < self.size - 1:
+            from_down = torch.empty(down.shape, dtype=down.dtype)
+            ops += [dist.P2POp(dist.isend, down.cpu(), self.rank + 1), dist.P2POp(dist.irecv, from_down, self.rank + 1)]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return (None if from_up is None else from_up.to(up.device),
+                None if from_down is None else from_down.to(down.device))
+
+    def all_gather_rows(self, x, rows):
+        mx = max(rows)
+        pad = torch.zeros((x.shape[0], mx) + tuple(x.shape[2:]), dtype=x.dtype)
+        pad[:, :x.shape[1]] = x.cpu()
+        parts = [torch.empty_like(pad) for _ in range(self.size)]
+        dist.all_gather(parts, pad)
+        return torch.cat([p[:, :n] for p, n in zip(parts, rows)], dim=1).to(x.device)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +162,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE decode leg")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--parallel", choices=["auto", "dp", "sp"], default="auto",
+                    help="with --gpus N > 1: dp = one video per GPU (no data-path collective); sp = one video "
+                         "over all N GPUs, Ulysses sequence parallelism; auto = sp for the A14B workloads "
+                         "(40 heads), dp for the 1.3B ones (12 heads do not divide by 8)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: every rank uses cuda:0 and the gloo backend, to exercise the "
                          "multi-rank control flow on a one-GPU box (numbers are meaningless)")
@@ -148,6 +193,13 @@ def main():
 
     wl = WORKLOADS[args.workload]
     cfg = syn.dit_config(wl["model"], text_len=wl["text_len"])
+    sp = world > 1 and (args.parallel == "sp" or (args.parallel == "auto" and wl["model"] == "A14B"))
+    comm = None
+    if sp:
+        if cfg["num_heads"] % world:
+            raise SystemExit(f"sequence parallelism needs the {cfg['num_heads']} heads to divide by {world} ranks")
+        from omnivideo.modules.engine import TorchGroupComm
+        comm = _CpuStagedComm() if args.rehearse_on_one_gpu else TorchGroupComm(None)
     K, W = args.steps, args.warmup
     if 1 + W + K > wl["steps"]:
         raise SystemExit(f"1 setup + {W} warmup + {K} timed steps exceed the workload's {wl['steps']} sampling steps")
@@ -155,7 +207,8 @@ def main():
     model = build_model(cfg, wl["text_len"], dev)
     precision = args.precision or wl.get("precision", "bf16")
     model.wan_model.linear_precision = precision
-    g = torch.Generator(device=dev).manual_seed(1818 + 1000 * rank)
+    # data parallel: a different video per rank; sequence parallel: every rank holds the same inputs
+    g = torch.Generator(device=dev).manual_seed(1818 + (0 if sp else 1000 * rank))
     rn = lambda *s: torch.randn(*s, device=dev, generator=g)
     special = {k: rn(1, cfg["text_dim"]).to(BF16) for k in ("<img_st>", "<img_ed>", "<prp_st>", "<prp_ed>")}
     ctx_c, ar_c = [rn(wl["n_text"], cfg["text_dim"]).to(BF16)], [rn(wl["n_vlm"], cfg["vlm_in_dim"]).to(BF16)]
@@ -171,8 +224,9 @@ def main():
         sched.set_timesteps(wl["steps"], device="cpu", shift=5.0)
         lat = noise.clone()
         seq_len = wl["latent"][1] * (wl["latent"][2] // 2) * (wl["latent"][3] // 2)
+        use_graph = not args.no_graph and not sp          # collectives are not captured
         loop = DenoiseLoop([model] * wl["steps"], lat, {id(model): (mixed_c, mixed_u)}, seq_len, sched, 3.0,
-                           use_graph=not args.no_graph)
+                           use_graph=use_graph, comm=comm)
         run = loop.run
 
         def fence():
@@ -197,7 +251,7 @@ def main():
         # ---- roofline of the dominant kernel (self-attention): HIP events around each launch
         # of a second, eager pass of K steps on the same stream
         roof = None
-        if rank == 0:
+        if rank == 0 or sp:          # under sequence parallelism the extra steps hold collectives: all ranks
             eng = loop.engines[id(model)]
             eng.timing = []
             for i in range(K):
@@ -206,7 +260,8 @@ def main():
             ms = [a.elapsed_time(b) for a, b in eng.timing]
             eng.timing = None
             L = seq_len
-            flops_launch = 4.0 * L * L * cfg["dim"] * 2            # batch of 2 guidance branches
+            # batch of 2 guidance branches; a sequence-parallel rank runs all rows for its share of the heads
+            flops_launch = 4.0 * L * L * cfg["dim"] * 2 / (world if sp else 1)
             avg_ms = sum(ms) / len(ms)
             ach = flops_launch / (avg_ms * 1e-3) / 1e12
             # HBM-side bytes per launch cannot be counted from here: they come from separate
@@ -227,10 +282,10 @@ def main():
             vae = Wan2_1_VAE(z_dim=16, vae_pth=None, device=dev)
         z = torch.randn(*wl["latent"], device=dev, generator=g)
         with torch.no_grad():
-            vae.decode([z])
+            vae.decode([z], comm=comm)           # under sequence parallelism: row-sharded over the group
             fence()
             t0 = time.perf_counter()
-            vae.decode([z])
+            vae.decode([z], comm=comm)
             fence()
             vae_s = time.perf_counter() - t0
         if world > 1:
@@ -240,7 +295,8 @@ def main():
         del vae
 
     ms_step = dt / K * 1e3
-    value = world * wl["frames"] / (wl["steps"] * ms_step * 1e-3)
+    videos = 1 if sp else world                  # videos in flight on the node
+    value = videos * wl["frames"] / (wl["steps"] * ms_step * 1e-3)
     if rank == 0:
         cache = loop.caches[id(model)]
         fl_fwd, fl_self = dit_flops_per_forward(cfg, seq_len, wl["text_len"])
@@ -248,15 +304,15 @@ def main():
         out = {
             "metric": "denoised frames/sec (whole node)", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "strong" if sp else "weak", "vs_baseline": None,
             "dtype": "bf16" if precision == "bf16" else "fp8 (e4m3 linear layers, bf16 attention, fp32 residual stream)",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "linear_precision": precision, "latent": list(wl["latent"]), "tokens": seq_len,
                        "context_len": wl["text_len"], "context_keys_read": cache.k_len, "sampling_steps": wl["steps"], "guide_scale": 3.0,
-                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "parallelism": (f"sp{world}" if sp else f"dp{world}") if world > 1 else "single",
                        "scope": "sampling loop (2 DiT forwards + CFG + UniPC per step); per-video context "
                                 "encode and VAE decode are outside the timed steps",
-                       "graph_replay": not args.no_graph},
+                       "graph_replay": use_graph},
             # algorithmic = the reference's work per step (2 forwards); executed = what the kernels ran
             "step_tflops": round(2 * fl_fwd / (ms_step * 1e-3) / 1e12, 1),
             "step_tflops_executed": round(2 * fl_exec / (ms_step * 1e-3) / 1e12, 1),
@@ -265,7 +321,7 @@ def main():
         }
         if vae_s is not None:
             out["vae_decode_s_per_video"] = round(vae_s, 3)
-            out["value_with_vae_decode"] = round(world * wl["frames"] / (wl["steps"] * ms_step * 1e-3 + vae_s), 4)
+            out["value_with_vae_decode"] = round(videos * wl["frames"] / (wl["steps"] * ms_step * 1e-3 + vae_s), 4)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, wl, args.cpu_threads)
         print(json.dumps(out))

@@ -377,11 +377,16 @@ int ovd_impl_quant_rows_fp8(const bf16_t* x, long ldx, uint8_t* q, long ldq, flo
     OVD_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K, "quant_rows_fp8: bad row strides");
     if (M == 0) return 0;
     dim3 grid(ceil_div(M, 4)), blk(256);
+    // registers per lane: the smallest instantiated row capacity (512 * V values) that holds K
     const int vpl = ceil_div(K, 512);
-#define Q_CASE(V) \
-    if (vpl <= V) { hipLaunchKernelGGL((quant_rows_fp8_kernel<V>), grid, blk, 0, st, x, ldx, q, ldq, scale, M, K); } else
-    Q_CASE(1) Q_CASE(3) Q_CASE(6) Q_CASE(10) Q_CASE(18) Q_CASE(28) {}
-#undef Q_CASE
+#define Q_LAUNCH(V) hipLaunchKernelGGL((quant_rows_fp8_kernel<V>), grid, blk, 0, st, x, ldx, q, ldq, scale, M, K)
+    if (vpl <= 1) Q_LAUNCH(1);
+    else if (vpl <= 3) Q_LAUNCH(3);
+    else if (vpl <= 6) Q_LAUNCH(6);
+    else if (vpl <= 10) Q_LAUNCH(10);
+    else if (vpl <= 18) Q_LAUNCH(18);
+    else Q_LAUNCH(28);
+#undef Q_LAUNCH
     OVD_CHECK_LAUNCH("quant_rows_fp8");
     return 0;
 }

@@ -352,7 +352,7 @@ def _f32c(t, allow_none=False):
     if t is None:
         return _ptr(None, allow_none=allow_none)
     if not t.is_contiguous():
-        raise ValueError("VAE kernels need contiguous tensors")
+        raise ValueError("this operator needs contiguous tensors")
     return _ptr(t, F32)
 
 
