@@ -215,20 +215,25 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
     }
 }
 
-// 1 / max(||x_v||_2, 1e-12) per voxel (F.normalize's denominator, vae2_1.py:50-53)
+// 1 / max(||x_v||_2, 1e-12) per voxel (F.normalize's denominator, vae2_1.py:50-53).  LPV lanes share
+// a voxel (LPV = the largest power of two dividing C/4, so every lane loads the same number of
+// float4s: 8 lanes x 3 for C = 96, 16 x 3 for 192, 32 x 3 for 384) and a wave covers 64/LPV voxels.
+template <int LPV>
 __global__ void __launch_bounds__(256) voxel_rnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           long nvox, int C) {
-    const int lane = threadIdx.x & 63;
-    const long v = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= nvox) return;
-    const float4* p = reinterpret_cast<const float4*>(x + v * C);
+    const int lane = threadIdx.x & 63, sub = lane % LPV;
+    const long v = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPV) + lane / LPV;
     float s = 0.f;
-    for (int i = lane; i < C / 4; i += 64) {
-        const float4 q = p[i];
-        s += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    if (v < nvox) {
+        const float4* p = reinterpret_cast<const float4*>(x + v * C);
+        for (int i = sub; i < C / 4; i += LPV) {
+            const float4 q = p[i];
+            s += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+        }
     }
-    s = wave_sum(s);
-    if (lane == 0) out[v] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+#pragma unroll
+    for (int o = LPV / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (v < nvox && sub == 0) out[v] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
 }
 
 // [C,T,H,W] -> [T,H,W,Cp] with out = (in + pre[c]) * mul[c] + post[c]; channels >= C are zero
@@ -389,7 +394,17 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
 int ovd_impl_voxel_rnorm(const float* x, float* out, long nvox, int C, hipStream_t st) {
     OVD_REQUIRE(C % 4 == 0 && C > 0, "voxel_rnorm: C must be a multiple of 4");
     if (nvox == 0) return 0;
-    hipLaunchKernelGGL(voxel_rnorm_kernel, dim3(ceil_div(nvox, 4)), dim3(256), 0, st, x, out, nvox, C);
+    const int q = C / 4;
+#define RN_CASE(L)                                                                                         \
+    hipLaunchKernelGGL(voxel_rnorm_kernel<L>, dim3(ceil_div(nvox, 4 * (64 / L))), dim3(256), 0, st, x, out, nvox, C)
+    if (q % 64 == 0) RN_CASE(64);
+    else if (q % 32 == 0) RN_CASE(32);
+    else if (q % 16 == 0) RN_CASE(16);
+    else if (q % 8 == 0) RN_CASE(8);
+    else if (q % 4 == 0) RN_CASE(4);
+    else if (q % 2 == 0) RN_CASE(2);
+    else RN_CASE(1);
+#undef RN_CASE
     OVD_CHECK_LAUNCH("voxel_rnorm");
     return 0;
 }
