@@ -12,7 +12,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *   - return value 0 = launched; non-zero = rejected before any launch, with the reason
  *     in ovd_last_error() (thread-local, valid until the next call on that thread);
- *   - strides (`ld*`, `*_bs`) are in ELEMENTS.
+ *   - strides (`ld*`, `*_bs`) are in ELEMENTS;
+ *   - two helpers do no GPU work and are marked HOST at their declaration
+ *     (ovd_resize_coeffs fills host tables, ovd_flash_attn_workspace_bytes returns a size).
  */
 #ifndef OMNIHIP_H
 #define OMNIHIP_H
