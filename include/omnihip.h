@@ -288,6 +288,19 @@ int ovd_vae_conv3d_f32(const float* x, const float* prev2, const float* prev1, c
                        int W, int Cin, int Cout, int KT, int KH, int KW, int stride_t, int stride_hw,
                        int pad_t, int pad_hw, int upsample2, int time_interleave, void* stream);
 
+/* The same convolution with its weights given in the split form of ovd_vae_split_weights, which is the
+ * image the kernel keeps in LDS: staging a weight slice is then a copy instead of a conversion
+ * repeated by every workgroup.  Results are bit-identical to ovd_vae_conv3d_f32 on its default
+ * (split-bf16) path; the exact-fp32 path (OVD_VAE_EXACT_FP32=1) needs the fp32 weights and rejects
+ * this entry.  ovd_vae_split_weights: w fp32 [rows][Cin] (rows = KT*KH*KW*Cout) ->
+ * out uint16 [rows][ceil(Cin/32)][32 hi | 32 lo] with hi = bf16(w), lo = bf16(w - hi), zero past Cin. */
+int ovd_vae_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, void* stream);
+int ovd_vae_conv3d_sw_f32(const float* x, const float* prev2, const float* prev1, const float* rnorm,
+                          const float* rnorm_prev2, const float* rnorm_prev1, const float* gamma, int silu,
+                          const uint16_t* w_split, const float* bias, const float* resid, float* out, int T, int H,
+                          int W, int Cin, int Cout, int KT, int KH, int KW, int stride_t, int stride_hw, int pad_t,
+                          int pad_hw, int upsample2, int time_interleave, void* stream);
+
 /* out[v] = 1 / max(||x[v,:]||_2, 1e-12) for nvox voxels of C channels: the denominator of
  * F.normalize in RMS_norm.forward (vae2_1.py:50-53). */
 int ovd_vae_voxel_rnorm(const float* x, float* out, int64_t nvox, int C, void* stream);

@@ -49,8 +49,9 @@ int ovd_impl_cfg_unipc_step(const float*, const float*, void*, void*, float*, fl
 int ovd_impl_cfg_dpm_step(const float*, const float*, const void*, float*, float*, const float*, float, const int*,
                           int, long, int, hipStream_t);
 int ovd_impl_step_advance(int*, hipStream_t);
+int ovd_impl_split_weights(const float*, uint16_t*, long, int, hipStream_t);
 int ovd_impl_conv3d_cl(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                       int, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int,
+                       int, const float*, const uint16_t*, const float*, const float*, float*, int, int, int, int, int, int, int, int,
                        int, int, int, int, int, int, hipStream_t);
 int ovd_impl_voxel_rnorm(const float*, float*, long, int, hipStream_t);
 int ovd_impl_to_cl(const float*, float*, const float*, const float*, const float*, int, int, long, hipStream_t);
@@ -287,9 +288,27 @@ int ovd_vae_conv3d_f32(const float* x, const float* prev2, const float* prev1, c
     NONNULL(x); NONNULL(w); NONNULL(out);
     OVD_REQUIRE((prev2 == nullptr || rnorm == nullptr) || rnorm_prev2 != nullptr, "conv3d: prev2 needs its voxel norms");
     OVD_REQUIRE((prev1 == nullptr || rnorm == nullptr) || rnorm_prev1 != nullptr, "conv3d: prev1 needs its voxel norms");
-    return ovd_impl_conv3d_cl(x, prev2, prev1, rnorm, rnorm_prev2, rnorm_prev1, gamma, silu, w, bias, resid, out, T, H,
-                              W, Cin, Cout, KT, KH, KW, stride_t, stride_hw, pad_t, pad_hw, upsample2, time_interleave,
-                              ST(stream));
+    return ovd_impl_conv3d_cl(x, prev2, prev1, rnorm, rnorm_prev2, rnorm_prev1, gamma, silu, w, nullptr, bias, resid, out,
+                              T, H, W, Cin, Cout, KT, KH, KW, stride_t, stride_hw, pad_t, pad_hw, upsample2,
+                              time_interleave, ST(stream));
+}
+
+int ovd_vae_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, void* stream) {
+    NONNULL(w); NONNULL(out);
+    return ovd_impl_split_weights(w, out, rows, Cin, ST(stream));
+}
+
+int ovd_vae_conv3d_sw_f32(const float* x, const float* prev2, const float* prev1, const float* rnorm,
+                          const float* rnorm_prev2, const float* rnorm_prev1, const float* gamma, int silu,
+                          const uint16_t* w_split, const float* bias, const float* resid, float* out, int T, int H,
+                          int W, int Cin, int Cout, int KT, int KH, int KW, int stride_t, int stride_hw, int pad_t,
+                          int pad_hw, int upsample2, int time_interleave, void* stream) {
+    NONNULL(x); NONNULL(w_split); NONNULL(out);
+    OVD_REQUIRE((prev2 == nullptr || rnorm == nullptr) || rnorm_prev2 != nullptr, "conv3d: prev2 needs its voxel norms");
+    OVD_REQUIRE((prev1 == nullptr || rnorm == nullptr) || rnorm_prev1 != nullptr, "conv3d: prev1 needs its voxel norms");
+    return ovd_impl_conv3d_cl(x, prev2, prev1, rnorm, rnorm_prev2, rnorm_prev1, gamma, silu, nullptr, w_split, bias, resid,
+                              out, T, H, W, Cin, Cout, KT, KH, KW, stride_t, stride_hw, pad_t, pad_hw, upsample2,
+                              time_interleave, ST(stream));
 }
 
 int ovd_vae_voxel_rnorm(const float* x, float* out, int64_t nvox, int C, void* stream) {

@@ -31,6 +31,7 @@ struct ConvArgs {
     const float* x; const float* prev2; const float* prev1;      // frames t>=0, t=-2, t=-1
     const float* rn; const float* rn_prev2; const float* rn_prev1;   // per-voxel 1/||x|| (or null)
     const float* gamma; const float* w; const float* bias; const float* resid; float* out;
+    const uint16_t* ws;                  // weights already split (ovd_vae_split_weights), or null
     int T, H, W, Cin, Cout, To, Ho, Wo;
     int KT, KH, KW, st, s, pt, ph;       // kernel, temporal stride, spatial stride, paddings
     int ups, til, silu, TW;              // input 2x upsample, time-interleaved output, SiLU, tile width
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
         hs0 = h0 * a.s - a.ph; ws0 = w0 * a.s - a.ph;
         HR = (TH - 1) * a.s + a.KH; WR = (TW - 1) * a.s + a.KW;
     }
-    float* wt = lds + HR * WR * LDV;             // [32*NB][LDV]
+    float* wt = lds + HR * WR * LDV;             // 2 x [32*NB][LDV]
 
     // this lane's output voxel inside the tile (A-operand row) and its halo index per tap
     const int iv = wave * 32 + (lane & 31);
@@ -129,25 +130,56 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
                 else *reinterpret_cast<float4*>(halo + v * LDV + 4 * j) = val;
             }
             const int ksteps = (min(32, a.Cin - cc * 32) + 7) >> 3;
+            // Weight slices [32*NB x 32] of the taps alternate between two LDS buffers: the slice of
+            // tap i + 1 is fetched into registers before the MFMAs of tap i and written to the other
+            // buffer after them, so a tap costs one barrier and its global loads fly behind the MFMAs.
+            // Each thread moves NB float4s per tap (32*NB rows x 8 float4 / 256 threads).
+            const int ntaps = a.KH * a.KW;
+            // With pre-split weights (a.ws: [tap][co][chunk][32 hi | 32 lo] bf16) a float4 is 16 raw
+            // bytes of that 128-byte row and goes to LDS as is; otherwise it is four fp32 weights,
+            // split while being written.
+            const bool pre_split = SPLIT && a.ws != nullptr;
+            auto w_ptr = [&](int tap_hw, int i) -> const float* {
+                const int idx = tid + i * 256, r = idx >> 3, j = idx & 7;
+                const int co = n0 + r, ci = cc * 32 + 4 * j;
+                if (co >= a.Cout) return nullptr;
+                if (pre_split)
+                    return reinterpret_cast<const float*>(
+                        a.ws + (((long)(kt * ntaps + tap_hw) * a.Cout + co) * nchunk + cc) * 64 + 8 * j);
+                if (ci >= a.Cin) return nullptr;
+                return a.w + ((long)(kt * ntaps + tap_hw) * a.Cout + co) * a.Cin + ci;
+            };
+            auto w_put = [&](float* buf, int i, const float4& val) {
+                const int idx = tid + i * 256, r = idx >> 3, j = idx & 7;
+                if (pre_split) *reinterpret_cast<float4*>(reinterpret_cast<char*>(buf + r * LDV) + 16 * j) = val;
+                else if (SPLIT) store_split4(reinterpret_cast<char*>(buf + r * LDV) + 8 * j, val);
+                else *reinterpret_cast<float4*>(buf + r * LDV + 4 * j) = val;
+            };
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const float* p = w_ptr(0, i);
+                w_put(wt, i, p ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+            __syncthreads();                      // halo and the first slice are in place
             for (int kh = 0; kh < a.KH; ++kh)
                 for (int kw = 0; kw < a.KW; ++kw) {
-                    const int tap = (kt * a.KH + kh) * a.KW + kw;
-                    if (kh + kw > 0) __syncthreads();          // wt is being re-staged
-                    for (int idx = tid; idx < 32 * NB * 8; idx += 256) {
-                        const int r = idx >> 3, j = idx & 7;
-                        const int co = n0 + r, ci = cc * 32 + 4 * j;
-                        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (co < a.Cout && ci < a.Cin)
-                            val = *reinterpret_cast<const float4*>(a.w + ((long)tap * a.Cout + co) * a.Cin + ci);
-                        if (SPLIT) store_split4(reinterpret_cast<char*>(wt + r * LDV) + 8 * j, val);
-                        else *reinterpret_cast<float4*>(wt + r * LDV + 4 * j) = val;
+                    const int tap_hw = kh * a.KW + kw;
+                    const float* wcur = wt + (tap_hw & 1) * (32 * NB * LDV);
+                    float* wnext = wt + ((tap_hw + 1) & 1) * (32 * NB * LDV);
+                    const bool has_next = tap_hw + 1 < ntaps;
+                    float4 pre[NB];
+                    if (has_next) {
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) {
+                            const float* p = w_ptr(tap_hw + 1, i);
+                            pre[i] = p ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
-                    __syncthreads();
                     int hsrc, wsrc;
                     if (a.ups) { hsrc = ((h0 + dh + kh - 1) >> 1) - hs0; wsrc = ((w0 + dw + kw - 1) >> 1) - ws0; }
                     else { hsrc = dh * a.s + kh; wsrc = dw * a.s + kw; }
                     const float* ap = halo + (hsrc * WR + wsrc) * LDV + 4 * kq;
-                    const float* bp = wt + (lane & 31) * LDV + 4 * kq;
+                    const float* bp = wcur + (lane & 31) * LDV + 4 * kq;
                     if (SPLIT) {
                         // lane (row/col = lane & 31, half kq) feeds k = 16*ks + 8*kq .. +7: 16 bytes
                         // at +32*ks + 16*kq of the hi plane, the lo plane 64 bytes further
@@ -184,6 +216,11 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
                     // registers across the branch (the last-written register came back stale with
                     // NB == 1).  32 wait states cover the 16-pass MFMA; < 3 % of a tap's MFMA time.
                     MFMA_DRAIN();
+                    if (has_next) {
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) w_put(wnext, i, pre[i]);
+                        __syncthreads();          // next slice visible; this one free for the tap after it
+                    }
                 }
         }
     }
@@ -234,6 +271,23 @@ __global__ void __launch_bounds__(256) voxel_rnorm_kernel(const float* __restric
 #pragma unroll
     for (int o = LPV / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (v < nvox && sub == 0) out[v] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+}
+
+// fp32 weights [rows][Cin] -> [rows][ceil(Cin/32)][32 hi | 32 lo] bf16 (zero beyond Cin): the image the
+// conv kernel puts into LDS, so that staging a weight slice is a copy
+__global__ void split_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, long rows, int Cin,
+                                     int nchunk) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * nchunk * 32) return;
+    const int k = (int)(idx & 31);
+    const long rc = idx >> 5;
+    const int cc = (int)(rc % nchunk);
+    const long r = rc / nchunk;
+    const int ci = cc * 32 + k;
+    uint32_t hi = 0, lo = 0;
+    if (ci < Cin) split_bf16(w[r * Cin + ci], hi, lo);
+    out[rc * 64 + k] = (uint16_t)hi;
+    out[rc * 64 + 32 + k] = (uint16_t)lo;
 }
 
 // [C,T,H,W] -> [T,H,W,Cp] with out = (in + pre[c]) * mul[c] + post[c]; channels >= C are zero
@@ -298,7 +352,8 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ s
 }  // namespace
 
 int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, const float* rn, const float* rn_prev2,
-                       const float* rn_prev1, const float* gamma, int silu, const float* w, const float* bias,
+                       const float* rn_prev1, const float* gamma, int silu, const float* w, const uint16_t* w_split,
+                       const float* bias,
                        const float* resid, float* out, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW,
                        int stride_t, int stride_hw, int pad_t, int pad_hw, int upsample2, int time_interleave,
                        hipStream_t st) {
@@ -318,7 +373,7 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
     OVD_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "conv3d: output would be empty");
     ConvArgs a;
     a.x = x; a.prev2 = prev2; a.prev1 = prev1; a.rn = rn; a.rn_prev2 = rn_prev2; a.rn_prev1 = rn_prev1;
-    a.gamma = gamma; a.w = w; a.bias = bias; a.resid = resid; a.out = out;
+    a.gamma = gamma; a.w = w; a.ws = w_split; a.bias = bias; a.resid = resid; a.out = out;
     a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.To = To; a.Ho = Ho; a.Wo = Wo;
     a.KT = KT; a.KH = KH; a.KW = KW; a.st = stride_t; a.s = stride_hw; a.pt = pad_t; a.ph = pad_hw;
     a.ups = upsample2; a.til = time_interleave; a.silu = silu;
@@ -362,7 +417,7 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
         }
         if (forced >= 1 && forced <= 4 && Cout % (32 * forced) == 0) nb = forced;
     }
-    const size_t lds = (size_t)(HR * WR + 32 * nb) * LDV * sizeof(float);
+    const size_t lds = (size_t)(HR * WR + 2 * 32 * nb) * LDV * sizeof(float);
     dim3 grid(tiles, ceil_div(Cout, 32 * nb)), blk(256);
     // split-bf16 products by default; OVD_VAE_EXACT_FP32=1 selects the exact fp32 matrix path
     static int exact = -1;
@@ -381,7 +436,10 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
         }                                                                                                      \
         hipLaunchKernelGGL((conv3d_cl_kernel<NBV, SPL>), grid, blk, lds, st, a);                               \
     } break;
+    OVD_REQUIRE(w != nullptr || (w_split != nullptr && !exact),
+                "conv3d: the exact-fp32 path (OVD_VAE_EXACT_FP32) needs the fp32 weights");
     if (exact) {
+        a.ws = nullptr;
         switch (nb) { CONV_CASE(1, false) CONV_CASE(2, false) CONV_CASE(3, false) CONV_CASE(4, false) }
     } else {
         switch (nb) { CONV_CASE(1, true) CONV_CASE(2, true) CONV_CASE(3, true) CONV_CASE(4, true) }
@@ -406,6 +464,15 @@ int ovd_impl_voxel_rnorm(const float* x, float* out, long nvox, int C, hipStream
     else RN_CASE(1);
 #undef RN_CASE
     OVD_CHECK_LAUNCH("voxel_rnorm");
+    return 0;
+}
+
+int ovd_impl_split_weights(const float* w, uint16_t* out, long rows, int Cin, hipStream_t st) {
+    OVD_REQUIRE(rows > 0 && Cin > 0, "split_weights: empty tensor");
+    const int nchunk = (Cin + 31) / 32;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(ceil_div(rows * nchunk * 32, 256)), dim3(256), 0, st, w, out, rows,
+                       Cin, nchunk);
+    OVD_CHECK_LAUNCH("split_weights");
     return 0;
 }
 

@@ -44,6 +44,8 @@ SIGNATURES = {
     "ovd_add_bf16": [_p, _p, _l, _p],
     "ovd_step_advance": [_p, _p],
     "ovd_vae_conv3d_f32": [_p] * 7 + [_i] + [_p] * 4 + [_i] * 14 + [_p],
+    "ovd_vae_conv3d_sw_f32": [_p] * 7 + [_i] + [_p] * 4 + [_i] * 14 + [_p],
+    "ovd_vae_split_weights": [_p, _p, _l, _i, _p],
     "ovd_vae_voxel_rnorm": [_p, _p, _l, _i, _p],
     "ovd_vae_to_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _p],
     "ovd_vae_from_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
@@ -356,11 +358,25 @@ def _f32c(t, allow_none=False):
     return _ptr(t, F32)
 
 
+class SplitWeight:
+    """Convolution weights [taps, Cout, Cin] in the split-bf16 form the conv kernel keeps in LDS
+    (ovd_vae_split_weights): `data` is uint16 [taps * Cout, ceil(Cin / 32), 64]."""
+
+    def __init__(self, w):
+        if w.dim() != 3 or w.dtype != F32 or not w.is_contiguous():
+            raise ValueError("SplitWeight: expected contiguous fp32 [taps, Cout, Cin]")
+        self.shape = tuple(w.shape)
+        taps, cout, cin = self.shape
+        self.data = torch.empty(taps * cout, (cin + 31) // 32, 64, dtype=torch.int16, device=w.device)
+        _call("ovd_vae_split_weights", _f32c(w), self.data.data_ptr(), taps * cout, cin, _stream())
+
+
 def vae_conv3d(x, w, bias, kernel, prev2=None, prev1=None, rnorm=None, rnorm_prev2=None, rnorm_prev1=None,
                gamma=None, silu=False, resid=None, stride_t=1, stride_hw=1, pad_t=0, pad_hw=0, upsample2=False,
                time_interleave=False, out=None):
     """x [T,H,W,Cin] fp32, w [KT*KH*KW, Cout, Cin] fp32 -> [To,Ho,Wo,Cout] (or the frame-interleaved
-    [2To,Ho,Wo,Cout/2]).  prev1/prev2 are the [H,W,Cin] frames at time -1/-2 (None = zeros)."""
+    [2To,Ho,Wo,Cout/2]).  prev1/prev2 are the [H,W,Cin] frames at time -1/-2 (None = zeros).
+    w may be a SplitWeight (same results, cheaper weight staging)."""
     T, H, W, Cin = x.shape
     KT, KH, KW = kernel
     taps, Cout, Cin_w = w.shape
@@ -380,8 +396,11 @@ def vae_conv3d(x, w, bias, kernel, prev2=None, prev1=None, rnorm=None, rnorm_pre
         raise ValueError(f"conv3d: out has shape {tuple(out.shape)}, expected {shape}")
     if resid is not None and tuple(resid.shape) != shape:
         raise ValueError("conv3d: residual shape mismatch")
-    _call("ovd_vae_conv3d_f32", _f32c(x), _f32c(prev2, True), _f32c(prev1, True), _f32c(rnorm, True),
-          _f32c(rnorm_prev2, True), _f32c(rnorm_prev1, True), _f32c(gamma, True), int(silu), _f32c(w),
+    split = isinstance(w, SplitWeight)
+    _call("ovd_vae_conv3d_sw_f32" if split else "ovd_vae_conv3d_f32", _f32c(x), _f32c(prev2, True),
+          _f32c(prev1, True), _f32c(rnorm, True),
+          _f32c(rnorm_prev2, True), _f32c(rnorm_prev1, True), _f32c(gamma, True), int(silu),
+          w.data.data_ptr() if split else _f32c(w),
           _f32c(bias, True), _f32c(resid, True), _f32c(out), T, H, W, Cin, Cout, KT, KH, KW, stride_t, stride_hw,
           pad_t, pad_hw, int(upsample2), int(time_interleave), _stream())
     return out

@@ -12,6 +12,7 @@ RMS norm + SiLU, the nearest 2x upsample, zero padding, bias, residual add and t
 temporal frame interleave are fused into the convolution kernel.
 """
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -227,9 +228,18 @@ class _Runner:
             t = wd.permute(2, 3, 4, 0, 1).reshape(-1, cout, cin)
             if cp != cin:
                 t = torch.cat([t, t.new_zeros(t.shape[0], cout, cp - cin)], dim=2)
-            hit = (ver, t.contiguous(), conv.bias.detach().to(F32).contiguous(), tuple(wd.shape[2:]))
+            t = t.contiguous()
+            # the kernel's default path multiplies split-bf16 operands: hand it the weights already split
+            # (the exact-fp32 path, OVD_VAE_EXACT_FP32=1, takes the fp32 weights)
+            tw = t if os.environ.get("OVD_VAE_EXACT_FP32", "0") not in ("", "0") else H.SplitWeight(t)
+            hit = (ver, tw, conv.bias.detach().to(F32).contiguous(), tuple(wd.shape[2:]), t)
             self._w[key] = hit
         return hit[1], hit[2], hit[3]
+
+    def weight_f32(self, conv):
+        """the fp32 [taps, Cout, Cin] weights (for callers that slice them)"""
+        self.weight(conv)
+        return self._w[id(conv)][4]
 
     def conv(self, x, conv, name=None, norm=None, silu=False, resid=None, **kw):
         """Causal conv with optional fused RMS-norm(+SiLU) on the input.  `name` keys the
@@ -270,7 +280,8 @@ class _Runner:
         L = Hh * Ww
         if L % 4:
             raise NotImplementedError("VAE attention needs h*w to be a multiple of 4")
-        wq, bq, _ = self.weight(blk.to_qkv)
+        _, bq, _ = self.weight(blk.to_qkv)
+        wq = self.weight_f32(blk.to_qkv)
         rn = H.vae_voxel_rnorm(x)
         gamma = blk.norm.gamma.detach().reshape(-1).to(F32).contiguous()
         parts = []
