@@ -214,3 +214,38 @@ def test_graph_replay_equals_eager_bitwise():
                                   size=(96, 64), frame_num=9, sampling_steps=6, guide_scale=3.0, seed=1, noise=noise,
                                   return_latents=True).clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_generate_returns_decoded_video_end_to_end():
+    """generate() with a VAE attached: sampling loop + decode in one call.  The video equals the VAE
+    decode of the latents the same call returns with return_latents=True, and tracks the oracle loop +
+    oracle VAE decode."""
+    from omnivideo.modules.vae2_1 import Wan2_1_VAE
+    from oracle import vae as V
+    cfg = syn.dit_config("tiny")
+    sd = syn.make_unified_state_dict(cfg, 0)
+    sp = syn.make_special_tokens(cfg, 0)
+    vcfg = syn.vae_config("tiny")
+    vsd = syn.make_vae_state_dict(vcfg, 0)
+    text, text_null = syn.randn("in.text", (10, cfg["text_dim"]), 1), syn.randn("in.text_null", (6, cfg["text_dim"]), 1)
+    noise = syn.randn("gen.noise", (16, 3, 8, 12), 11).to(BF16)
+    pipe = _pipeline(cfg, sd, sp)
+    pipe.vae = Wan2_1_VAE(z_dim=vcfg["z_dim"], vae_pth=None, device="cuda", dim=vcfg["dim"])
+    pipe.vae.model.load_state_dict(vsd, strict=True)
+    kw = dict(precomputed_context=text.to(BF16), precomputed_context_null=text_null.to(BF16), size=(96, 64),
+              frame_num=9, shift=5.0, sampling_steps=3, guide_scale=3.0, seed=1, noise=noise)
+    video = pipe.generate("", **kw)
+    assert video.dtype == F32 and tuple(video.shape) == (3, 9, 64, 96)
+    assert float(video.min()) >= -1.0 and float(video.max()) <= 1.0
+    lat = pipe.generate("", return_latents=True, **kw)
+    assert torch.equal(video, pipe.vae.decode([lat])[0])
+    sdb = O.round_weights_bf16(sd)
+    rbw = lambda t: t.to(BF16).float()
+    fc = lambda l, t: O.unified_forward(l.float(), t, sdb, cfg, 72, "bf16", text=rbw(text))
+    fu = lambda l, t: O.unified_forward(l.float(), t, sdb, cfg, 72, "bf16", text=rbw(text_null))
+    ref_lat = U.sample_loop(fc, fu, noise.clone(), 3, 5.0, 3.0)
+    lay = V.vae_layout(vcfg["dim"], vcfg["z_dim"], vcfg["dim_mult"], vcfg["num_res_blocks"], vcfg["temperal_downsample"])
+    with torch.no_grad():
+        ref_video = V.decode(ref_lat.float(), vsd, lay).clamp(-1, 1)
+    rel = float((video.cpu() - ref_video).norm() / ref_video.norm())
+    assert rel < 3e-2, rel
