@@ -249,3 +249,42 @@ def test_generate_returns_decoded_video_end_to_end():
         ref_video = V.decode(ref_lat.float(), vsd, lay).clamp(-1, 1)
     rel = float((video.cpu() - ref_video).norm() / ref_video.norm())
     assert rel < 3e-2, rel
+
+
+def test_v2v_input_path_frames_to_latents_to_generate():
+    """The V2V input chain of the reference's CLI (tools/inference/generate_omni_v2v.py:597-640): source
+    frames -> crop/resize/normalise -> VAE encode -> visual_emb -> generate(), against the same chain in
+    the oracle (Pillow-exact resize, oracle encode, oracle loop)."""
+    from omnivideo.modules.vae2_1 import Wan2_1_VAE
+    from omnivideo.utils.utils import transform_frames_to_tensor
+    from oracle import vae as V
+    from oracle import video as OV
+    cfg = syn.dit_config("tiny")
+    sd, sp = syn.make_unified_state_dict(cfg, 0), syn.make_special_tokens(cfg, 0)
+    vcfg = syn.vae_config("tiny")
+    vsd = syn.make_vae_state_dict(vcfg, 0)
+    lay = V.vae_layout(vcfg["dim"], vcfg["z_dim"], vcfg["dim_mult"], vcfg["num_res_blocks"], vcfg["temperal_downsample"])
+    frames = syn.make_frames("v2v.src", 9, 70, 110)
+    pipe = _pipeline(cfg, sd, sp)
+    pipe.vae = Wan2_1_VAE(z_dim=vcfg["z_dim"], vae_pth=None, device="cuda", dim=vcfg["dim"])
+    pipe.vae.model.load_state_dict(vsd, strict=True)
+    ft = transform_frames_to_tensor(frames, (64, 96))                       # [T, 3, h, w] on the device
+    assert torch.equal(ft.cpu(), OV.transform_frames_to_tensor(frames, (64, 96)))
+    latent = pipe.vae.encode([ft.transpose(0, 1)])[0]                        # [16, 3, 8, 12]
+    assert tuple(latent.shape) == (16, 3, 8, 12)
+    with torch.no_grad():
+        ref_latent = V.encode(OV.transform_frames_to_tensor(frames, (64, 96)).transpose(0, 1).contiguous(), vsd, lay)
+    torch.testing.assert_close(latent.cpu(), ref_latent, rtol=1e-3, atol=1e-4)
+    text, text_null = syn.randn("in.text", (10, cfg["text_dim"]), 1), syn.randn("in.text_null", (6, cfg["text_dim"]), 1)
+    noise = syn.randn("gen.noise", (16, 3, 8, 12), 11).to(BF16)
+    lat = pipe.generate("", precomputed_context=text.to(BF16), precomputed_context_null=text_null.to(BF16),
+                        visual_emb=latent[None], size=(96, 64), frame_num=9, shift=5.0, sampling_steps=3,
+                        guide_scale=3.0, seed=1, noise=noise, return_latents=True)
+    sdb = O.round_weights_bf16(sd)
+    rbw = lambda t: t.to(BF16).float()
+    vis = ref_latent[None]
+    fc = lambda l, t: O.unified_forward(l.float(), t, sdb, cfg, 72, "bf16", text=rbw(text), visual=vis, special=sp)
+    fu = lambda l, t: O.unified_forward(l.float(), t, sdb, cfg, 72, "bf16", text=rbw(text_null), visual=vis, special=sp)
+    ref = U.sample_loop(fc, fu, noise.clone(), 3, 5.0, 3.0)
+    rel = float((lat.float().cpu() - ref.float()).norm() / ref.float().norm())
+    assert rel < 2e-2, rel
