@@ -111,3 +111,46 @@ def test_encoder_model_wrapper_and_mask_semantics():
         enc(["a prompt"], "cuda")
     with pytest.raises(NotImplementedError, match="prefix"):
         enc.model(ids.cuda(), torch.tensor([[1, 0] * 16, [1] * 32]).cuda())
+
+
+def test_generate_encodes_prompts_with_the_attached_text_encoder():
+    """generate() without precomputed contexts calls self.text_encoder for the prompt and the negative
+    prompt (reference x2x_gen_unified.py:336-352); the result equals passing the same embeddings in."""
+    from omnivideo.configs import Config, t2v_1_3B
+    from omnivideo.modules.t5 import T5EncoderModel
+    from omnivideo.x2x_gen_unified_1_3B import OmniVideoX2XUnified1_3B
+    dcfg = syn.dit_config("tiny")
+    tcfg = syn.t5_config("tiny")
+    assert tcfg["dim"] == dcfg["text_dim"]
+
+    def tokenizer(texts, return_mask=True, add_special_tokens=True):
+        """stand-in for HuggingfaceTokenizer: bytes as ids, end token 1, padded to 32 with a prefix mask"""
+        ids, mask = torch.zeros(len(texts), 32, dtype=torch.long), torch.zeros(len(texts), 32, dtype=torch.long)
+        for i, t in enumerate(texts):
+            toks = [2 + (b % 250) for b in t.encode()][:31] + [1]
+            ids[i, :len(toks)] = torch.tensor(toks)
+            mask[i, :len(toks)] = 1
+        return ids, mask
+
+    enc = T5EncoderModel(text_len=32, device="cuda", tokenizer=tokenizer, vocab_size=tcfg["vocab_size"],
+                         dim=tcfg["dim"], dim_attn=tcfg["dim_attn"], dim_ffn=tcfg["dim_ffn"],
+                         num_heads=tcfg["num_heads"], encoder_layers=tcfg["num_layers"],
+                         num_buckets=tcfg["num_buckets"])
+    enc.model.load_state_dict(syn.make_t5_state_dict(tcfg, 0), strict=True)
+    enc.model.to(BF16)
+    pipe = OmniVideoX2XUnified1_3B(Config(t2v_1_3B), None, vlm_in_dim=dcfg["vlm_in_dim"],
+                                   use_visual_context_adapter=True,
+                                   visual_context_adapter_patch_size=dcfg["visual_patch_size"],
+                                   max_context_len=dcfg["text_len"], wan_config=dict(dcfg))
+    pipe.model.load_state_dict(syn.make_unified_state_dict(dcfg, 0), strict=True)
+    pipe.model.to(BF16)
+    pipe.text_encoder = enc
+    noise = syn.randn("gen.noise", (16, 3, 8, 12), 11).to(BF16)
+    kw = dict(size=(96, 64), frame_num=9, shift=5.0, sampling_steps=2, guide_scale=3.0, seed=1, noise=noise,
+              return_latents=True)
+    prompt, neg = "a person playing guitar", "blurry, low quality"
+    a = pipe.generate(prompt, n_prompt=neg, **kw)
+    c, u = enc([prompt], "cuda")[0], enc([neg], "cuda")[0]
+    assert c.shape[0] == len(prompt) + 1 and u.shape[0] == len(neg) + 1
+    b = pipe.generate("", precomputed_context=c, precomputed_context_null=u, **kw)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
