@@ -374,8 +374,11 @@ class DiTEngine:
                 H.gemm(self.h, L["w_cq"], qc, L["b_cq"], H.EPI_BF16)
             H.rmsnorm_rope(qc, L["cnq"], qc, D, self.eps)
             kvl = ctx.kv[l]
+            # (the workspace only matters for long contexts - V2V with thousands of visual tokens - and
+            # for the unsharded case: it is sized for all N heads over seq_len query rows)
             H.flash_attn(q4, kvl[:, :, :C].unflatten(2, (N, D)), kvl[:, :, C:].unflatten(2, (N, D)), att4,
-                         k_len=ctx.k_len, last_key_copies=ctx.last_key_copies)
+                         k_len=ctx.k_len, last_key_copies=ctx.last_key_copies,
+                         workspace=self.attn_ws if self.sp == 1 else None)
             self._linear_from_attention(att2, L, "co")
             pending = (self.res, None)
             # feed-forward (model.py:251-254)
