@@ -15,8 +15,16 @@ BF16 = torch.bfloat16
 
 
 def timeit(fn, iters=10, warm=2):
-    for _ in range(warm):
+    # the first launches after an idle period run at a low clock: warm up for at least 0.3 s
+    import time
+    t0 = time.time()
+    n = 0
+    while n < warm or time.time() - t0 < 0.3:
         fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     a.record()
