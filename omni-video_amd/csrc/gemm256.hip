@@ -243,30 +243,35 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
         // c ^ ((r >> 1) & 7): the writes are 2 lanes per bank (the minimum for 512 B), the reads
         // conflict-free.
         char* ep = smem + wave * 16384;
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                float y[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) y[j] = acc[nt][mt][j] + bv[nt][j];
-                if (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(round_bf(y[j]));
-                }
-                uint2 o;
-                o.x = pack_bf2(y[0], y[1]);
-                o.y = pack_bf2(y[2], y[3]);
-                const int r = mt * 16 + fr, c = nt * 2 + (fq >> 1);
-                *reinterpret_cast<uint2*>(ep + r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + (fq & 1) * 8) = o;
-            }
         const int rr = lane >> 3, cc = lane & 7;
         bf16_t* ob = reinterpret_cast<bf16_t*>(out) + (long)(row0 + wr * 128) * ldo + col0 + wc * 64 + cc * 8;
+        // two halves of 64 rows: the stores of the first half are in flight while the second half is
+        // being computed (the GELU is ~40 VALU cycles per element)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = i * 8 + rr;
-            const uint4 v = *reinterpret_cast<const uint4*>(ep + r * 128 + ((cc ^ ((r >> 1) & 7)) << 4));
-            if (row0 + wr * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)r * ldo) = v;
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int mt = 4 * hf; mt < 4 * hf + 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float y[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = acc[nt][mt][j] + bv[nt][j];
+                    if (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(round_bf(y[j]));
+                    }
+                    uint2 o;
+                    o.x = pack_bf2(y[0], y[1]);
+                    o.y = pack_bf2(y[2], y[3]);
+                    const int r = mt * 16 + fr, c = nt * 2 + (fq >> 1);
+                    *reinterpret_cast<uint2*>(ep + r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + (fq & 1) * 8) = o;
+                }
+#pragma unroll
+            for (int i = 8 * hf; i < 8 * hf + 8; ++i) {
+                const int r = i * 8 + rr;
+                const uint4 v = *reinterpret_cast<const uint4*>(ep + r * 128 + ((cc ^ ((r >> 1) & 7)) << 4));
+                if (row0 + wr * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)r * ldo) = v;
+            }
         }
         return;
     }
