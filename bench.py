@@ -274,6 +274,24 @@ def main():
                     "traffic": traffic, "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4),
                     "flop_per_launch": flops_launch}
 
+    # ---- second-largest kernel family: the FFN-up GEMM (+ GELU) of one layer on the step's own buffers
+    roof2 = None
+    if rank == 0 and precision == "bf16" and not sp:
+        eng = loop.engines[id(model)]
+        Lw = eng.layers[0]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        with torch.no_grad():
+            for a, b in ev:
+                a.record()
+                H.gemm(eng.h, Lw["w_f0"], eng.ffn, Lw["b_f0"], H.EPI_BF16_GELU)
+                b.record()
+        torch.cuda.synchronize()
+        ms2 = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+        fl2 = 2.0 * eng.h.shape[0] * cfg["ffn_dim"] * cfg["dim"]
+        roof2 = {"bound": "mfma", "kernel": "gemm256_kernel<GELU> (FFN-up, one layer)", "achieved": round(fl2 / ms2 / 1e9, 1),
+                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl2 / ms2 / 1e9 / PEAK_BF16_TFLOPS, 4),
+                 "median_launch_ms": round(ms2, 4), "flop_per_launch": fl2}
+
     # ---- VAE decode of one video's latent (random-init full-width VAE), reported beside the loop
     vae_s = None
     if not args.no_vae:
@@ -319,6 +337,8 @@ def main():
             "step_mfma_frac_executed": round(2 * fl_exec / (ms_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": roof,
         }
+        if roof2 is not None:
+            out["roofline_gemm"] = roof2
         if vae_s is not None:
             out["vae_decode_s_per_video"] = round(vae_s, 3)
             out["value_with_vae_decode"] = round(videos * wl["frames"] / (wl["steps"] * ms_step * 1e-3 + vae_s), 4)
