@@ -25,6 +25,19 @@
 // more than RESCALE_THR (log2 units): probabilities then stay below 2^THR, which costs no
 // relative precision in bf16/fp32, and the 64-register rescale of O is skipped on almost
 // every tile.
+//
+// Output: the normalised O^T accumulators are written as bf16 into the wave's (by then
+// free) LDS region with a per-row chunk swizzle and read back row-major, so each lane
+// stores 16 bytes and a store instruction covers whole 256-byte head rows instead of
+// 8-byte pieces in accumulator order.
+//
+// Tail balancing: all workgroups of a launch take the same time, so a grid that is not a
+// multiple of the CU count ends in a partly filled round.  When attn_split_plan() finds
+// such a tail, the trailing query blocks of every XCD are split over the two halves of the
+// key range (those workgroups are dispatched last); each half writes its unnormalised O,
+// running maximum and sum to a caller-owned workspace and attn_merge_kernel combines the
+// two in the exp2 domain.  Launches with few workgroups, or with at most 1024 keys
+// (cross-attention), use 4-wave workgroups so more of them fit the chip.
 #include "common.h"
 
 namespace {
