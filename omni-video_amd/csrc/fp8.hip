@@ -15,7 +15,7 @@
 // stagger of the two wave groups are byte-identical; a K-tile now holds 64 k-values and is
 // consumed by 8 v_mfma_scale_f32_32x32x64_f8f6f4 per wave (unit block scales), which take the
 // time of the 32 bf16 MFMAs they replace for twice the K.
-#include "common.h"
+#include "ln_row.h"
 
 namespace {
 
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) quant_rows_fp8_kernel(const bf16_t* __res
 
 // LayerNorm (+ affine) (+ modulation) as ln_mod_kernel of norm.hip computes it, rounded to bf16 as
 // that kernel's output is, then quantised per row.
-template <int VPL, bool RES>
+template <int VPL, int WPR, int F>
 __global__ void __launch_bounds__(256) ln_mod_fp8_kernel(float* __restrict__ x, long ldx,
                                                          const bf16_t* __restrict__ res, long ldr,
                                                          const float* __restrict__ res_gate,
@@ -91,76 +91,39 @@ __global__ void __launch_bounds__(256) ln_mod_fp8_kernel(float* __restrict__ x, 
                                                          uint8_t* __restrict__ out, long ldo,
                                                          float* __restrict__ row_scale, int M, int C, float eps,
                                                          int round_norm) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float4* xr = reinterpret_cast<float4*>(x + (long)row * ldx);
-    float4 v[VPL];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        v[i] = xr[i * 64 + lane];
-        if (RES) {                       // pending residual update, as in ln_mod_kernel of norm.hip
-            const uint2 rp = *reinterpret_cast<const uint2*>(res + (long)row * ldr + (i * 64 + lane) * 4);
-            float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (res_gate) g = *reinterpret_cast<const float4*>(res_gate + (i * 64 + lane) * 4);
-            v[i].x = fmaf(bf2f(rp.x & 0xffff), g.x, v[i].x);
-            v[i].y = fmaf(bf2f(rp.x >> 16), g.y, v[i].y);
-            v[i].z = fmaf(bf2f(rp.y & 0xffff), g.z, v[i].z);
-            v[i].w = fmaf(bf2f(rp.y >> 16), g.w, v[i].w);
-            xr[i * 64 + lane] = v[i];
-        }
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    __shared__ float red[3][4];
+    float4 y[VPL];
+    int row;
+    const bool live =
+        ln_row<VPL, WPR, F>(x, ldx, res, ldr, res_gate, shift, scale, w, b, M, C, eps, round_norm, red, row, y);
+    if constexpr (WPR == 1) {
+        if (!live) return;
     }
-    const float mean = wave_sum(s) / (float)C;
-    float qq = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-        qq += (a * a + bb * bb) + (c * c + d * d);
-    }
-    const float rstd = rsqrtf(wave_sum(qq) / (float)C + eps);
     float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int col = (i * 64 + lane) * 4;
-        float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd,
-                      (v[i].w - mean) * rstd};
-        if (w) {
-            const uint2 wp = *reinterpret_cast<const uint2*>(w + col);
-            const uint2 bp = *reinterpret_cast<const uint2*>(b + col);
-            y[0] = y[0] * bf2f(wp.x & 0xffff) + bf2f(bp.x & 0xffff);
-            y[1] = y[1] * bf2f(wp.x >> 16) + bf2f(bp.x >> 16);
-            y[2] = y[2] * bf2f(wp.y & 0xffff) + bf2f(bp.y & 0xffff);
-            y[3] = y[3] * bf2f(wp.y >> 16) + bf2f(bp.y >> 16);
-        }
-        if (round_norm) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = round_bf(y[j]);
-        }
-        if (scale) {
-            const float4 sc = *reinterpret_cast<const float4*>(scale + col);
-            const float4 sh = *reinterpret_cast<const float4*>(shift + col);
-            y[0] = y[0] * (1.f + sc.x) + sh.x;
-            y[1] = y[1] * (1.f + sc.y) + sh.y;
-            y[2] = y[2] * (1.f + sc.z) + sh.z;
-            y[3] = y[3] * (1.f + sc.w) + sh.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            y[j] = round_bf(y[j]);
-            mx = fmaxf(mx, fabsf(y[j]));
-        }
-        v[i] = make_float4(y[0], y[1], y[2], y[3]);
+        y[i] = make_float4(round_bf(y[i].x), round_bf(y[i].y), round_bf(y[i].z), round_bf(y[i].w));
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(y[i].x), fabsf(y[i].y)), fmaxf(fabsf(y[i].z), fabsf(y[i].w))));
     }
-    mx = wave_max(mx);
+    mx = row_max<WPR>(mx, red[2]);
+    if (!live) return;
     const float sq = mx > 0.f ? mx / FP8_MAX : 1.f;
     const float inv = 1.f / sq;
-    if (lane == 0) row_scale[row] = sq;
+    if ((threadIdx.x & (64 * WPR - 1)) == 0) row_scale[row] = sq;
 #pragma unroll
     for (int i = 0; i < VPL; ++i)
-        *reinterpret_cast<uint32_t*>(out + (long)row * ldo + (i * 64 + lane) * 4) =
-            pack_fp8x4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+        *reinterpret_cast<uint32_t*>(out + (long)row * ldo + ln_piece<WPR>(i) * 4) =
+            pack_fp8x4(y[i].x * inv, y[i].y * inv, y[i].z * inv, y[i].w * inv);
+}
+
+template <int V, int WPR, typename... A>
+static void launch_ln_fp8_flags(int flags, int M, hipStream_t st, A... a) {
+    const dim3 grid(ceil_div(M, 4 / WPR)), blk(256);
+    switch (flags) {
+#define LN_F(F) case F: hipLaunchKernelGGL((ln_mod_fp8_kernel<V, WPR, F>), grid, blk, 0, st, a...); break;
+        LN_FOR_EACH_FLAGS(LN_F)
+#undef LN_F
+    }
 }
 
 // ------------------------------------------------------------------------------------- GEMM
@@ -401,18 +364,14 @@ int ovd_impl_ln_fp8(float* x, long ldx, const bf16_t* res, long ldr, const float
     OVD_REQUIRE((scale == nullptr) == (shift == nullptr), "layernorm fp8: scale and shift must come together");
     OVD_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "layernorm fp8: row strides must be multiples of 4");
     if (M == 0) return 0;
-    dim3 grid(ceil_div(M, 4)), blk(256);
-#define LN_CASE(V)                                                                                          \
-    case V:                                                                                                 \
-        if (res)                                                                                            \
-            hipLaunchKernelGGL((ln_mod_fp8_kernel<V, true>), grid, blk, 0, st, x, ldx, res, ldr, res_gate,     \
-                               shift, scale, w, b, out, ldo, row_scale, M, C, eps, round_norm);             \
-        else                                                                                                \
-            hipLaunchKernelGGL((ln_mod_fp8_kernel<V, false>), grid, blk, 0, st, x, ldx, res, ldr, res_gate,    \
-                               shift, scale, w, b, out, ldo, row_scale, M, C, eps, round_norm);             \
+    const int flags = (res ? LN_RES : 0) | (res_gate ? LN_GATE : 0) | (w ? LN_AFF : 0) | (scale ? LN_MOD : 0);
+#define LN_CASE(V, WPR)                                                                                       \
+    case V * WPR:                                                                                             \
+        launch_ln_fp8_flags<V, WPR>(flags, M, st, x, ldx, res, ldr, res_gate, shift, scale, w, b, out, ldo,   \
+                                    row_scale, M, C, eps, round_norm);                                        \
         break;
     switch (C / 256) {
-        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(6) LN_CASE(8) LN_CASE(12) LN_CASE(16) LN_CASE(20)
+        LN_FOR_EACH_SHAPE(LN_CASE)
         default:
             OVD_FAIL("layernorm fp8: unsupported width C=%d", C);
     }

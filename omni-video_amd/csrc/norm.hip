@@ -1,7 +1,7 @@
-// Row-wise normalisation kernels (HBM-bound): one 64-lane wave owns one token row,
-// the row lives in registers between the statistics pass and the write pass, loads
-// and stores are 16 bytes per lane.
-#include "common.h"
+// Row-wise normalisation kernels (HBM-bound): one 64-lane wave owns one token row (wide
+// LayerNorm rows: two or four waves share it), the row lives in registers between the
+// statistics pass and the write pass, loads are 16 bytes per lane.
+#include "ln_row.h"
 
 // ---------------------------------------------------------------------------------
 // LayerNorm (biased variance, fp32) + optional affine (bf16 params) + optional
@@ -10,11 +10,8 @@
 // modulation of WanAttentionBlock.forward (:243,252) and Head.forward (:287-289).
 // round_norm: the block-0 case where the LayerNorm input is a bf16 tensor and the
 // normalised value is cast back to bf16 before the modulation.
-// RES: the pending residual update of the layer before this norm is applied on the way in,
-// x[m][c] += res[m][c] * res_gate[c] (res bf16 = the rounded output of that layer's last Linear,
-// model.py:245-246,250,253-254), written back to x and then normalised - one pass over x
-// instead of a read-modify-write in the GEMM epilogue followed by this kernel's read.
-template <int VPL, typename OutT, bool RES>
+// Row arithmetic: ln_row() of ln_row.h.
+template <int VPL, int WPR, typename OutT, int F>
 __global__ void __launch_bounds__(256) ln_mod_kernel(float* __restrict__ x, long ldx,
                                                      const bf16_t* __restrict__ res, long ldr,
                                                      const float* __restrict__ res_gate,
@@ -23,68 +20,39 @@ __global__ void __launch_bounds__(256) ln_mod_kernel(float* __restrict__ x, long
                                                      const bf16_t* __restrict__ w,
                                                      const bf16_t* __restrict__ b, OutT* __restrict__ out,
                                                      long ldo, int M, int C, float eps, int round_norm) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float4* xr = reinterpret_cast<float4*>(x + (long)row * ldx);
-    float4 v[VPL];
-    float s = 0.f;
+    __shared__ float red[2][4];
+    float4 y[VPL];
+    int row;
+    if (!ln_row<VPL, WPR, F>(x, ldx, res, ldr, res_gate, shift, scale, w, b, M, C, eps, round_norm, red, row, y))
+        return;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        v[i] = xr[i * 64 + lane];
-        if (RES) {
-            const uint2 rp = *reinterpret_cast<const uint2*>(res + (long)row * ldr + (i * 64 + lane) * 4);
-            float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (res_gate) g = *reinterpret_cast<const float4*>(res_gate + (i * 64 + lane) * 4);
-            v[i].x = fmaf(bf2f(rp.x & 0xffff), g.x, v[i].x);
-            v[i].y = fmaf(bf2f(rp.x >> 16), g.y, v[i].y);
-            v[i].z = fmaf(bf2f(rp.y & 0xffff), g.z, v[i].z);
-            v[i].w = fmaf(bf2f(rp.y >> 16), g.w, v[i].w);
-            xr[i * 64 + lane] = v[i];
-        }
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-        q += (a * a + bb * bb) + (c * c + d * d);
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int col = (i * 64 + lane) * 4;
-        float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd,
-                      (v[i].w - mean) * rstd};
-        if (w) {
-            const uint2 wp = *reinterpret_cast<const uint2*>(w + col);
-            const uint2 bp = *reinterpret_cast<const uint2*>(b + col);
-            y[0] = y[0] * bf2f(wp.x & 0xffff) + bf2f(bp.x & 0xffff);
-            y[1] = y[1] * bf2f(wp.x >> 16) + bf2f(bp.x >> 16);
-            y[2] = y[2] * bf2f(wp.y & 0xffff) + bf2f(bp.y & 0xffff);
-            y[3] = y[3] * bf2f(wp.y >> 16) + bf2f(bp.y >> 16);
-        }
-        if (round_norm) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = round_bf(y[j]);
-        }
-        if (scale) {
-            const float4 sc = *reinterpret_cast<const float4*>(scale + col);
-            const float4 sh = *reinterpret_cast<const float4*>(shift + col);
-            y[0] = y[0] * (1.f + sc.x) + sh.x;
-            y[1] = y[1] * (1.f + sc.y) + sh.y;
-            y[2] = y[2] * (1.f + sc.z) + sh.z;
-            y[3] = y[3] * (1.f + sc.w) + sh.w;
-        }
+        const int col = ln_piece<WPR>(i) * 4;
         if constexpr (sizeof(OutT) == 2) {
             uint2 o;
-            o.x = pack_bf2(y[0], y[1]);
-            o.y = pack_bf2(y[2], y[3]);
+            o.x = pack_bf2(y[i].x, y[i].y);
+            o.y = pack_bf2(y[i].z, y[i].w);
             *reinterpret_cast<uint2*>(out + (long)row * ldo + col) = o;
         } else {
-            *reinterpret_cast<float4*>(out + (long)row * ldo + col) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(out + (long)row * ldo + col) = y[i];
         }
+    }
+}
+
+template <int V, int WPR, typename OutT, int F>
+static void launch_ln_one(hipStream_t st, float* x, long ldx, const bf16_t* res, long ldr,
+                          const float* res_gate, const float* shift, const float* scale, const bf16_t* w,
+                          const bf16_t* b, OutT* out, long ldo, int M, int C, float eps, int round_norm) {
+    hipLaunchKernelGGL((ln_mod_kernel<V, WPR, OutT, F>), dim3(ceil_div(M, 4 / WPR)), dim3(256), 0, st, x, ldx,
+                       res, ldr, res_gate, shift, scale, w, b, out, ldo, M, C, eps, round_norm);
+}
+
+template <int V, int WPR, typename OutT, typename... A>
+static void launch_ln_flags(int flags, A... a) {
+    switch (flags) {
+#define LN_F(F) case F: launch_ln_one<V, WPR, OutT, F>(a...); break;
+        LN_FOR_EACH_FLAGS(LN_F)
+#undef LN_F
     }
 }
 
@@ -99,18 +67,15 @@ static int launch_ln(float* x, long ldx, const bf16_t* res, long ldr, const floa
     OVD_REQUIRE((scale == nullptr) == (shift == nullptr), "layernorm: scale and shift must come together");
     OVD_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "layernorm: row strides must be multiples of 4");
     if (M == 0) return 0;
-    dim3 grid(ceil_div(M, 4)), blk(256);
-#define LN_CASE(V)                                                                                         \
-    case V:                                                                                                \
-        if (res)                                                                                           \
-            hipLaunchKernelGGL((ln_mod_kernel<V, OutT, true>), grid, blk, 0, st, x, ldx, res, ldr, res_gate,  \
-                               shift, scale, w, b, out, ldo, M, C, eps, round_norm);                       \
-        else                                                                                               \
-            hipLaunchKernelGGL((ln_mod_kernel<V, OutT, false>), grid, blk, 0, st, x, ldx, res, ldr, res_gate, \
-                               shift, scale, w, b, out, ldo, M, C, eps, round_norm);                       \
+    const int flags = (res ? LN_RES : 0) | (res_gate ? LN_GATE : 0) | (w ? LN_AFF : 0) | (scale ? LN_MOD : 0);
+    // C = 256 * V * WPR: V pieces of 16 bytes per lane, WPR waves per row
+#define LN_CASE(V, WPR)                                                                                   \
+    case V * WPR:                                                                                         \
+        launch_ln_flags<V, WPR, OutT>(flags, st, x, ldx, res, ldr, res_gate, shift, scale, w, b, out, ldo, M, \
+                                      C, eps, round_norm);                                                \
         break;
     switch (C / 256) {
-        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(6) LN_CASE(8) LN_CASE(12) LN_CASE(16) LN_CASE(20)
+        LN_FOR_EACH_SHAPE(LN_CASE)
         default:
             OVD_FAIL("layernorm: unsupported width C=%d", C);
     }
@@ -141,25 +106,58 @@ int ovd_impl_ln_f32(float* x, long ldx, const bf16_t* res, long ldr, const float
 // it owns inside a head (frame: first D/2 - 2*(D/6) pairs, then height, then width).
 // Token index = (row % rows_per_sample) + tok_offset; rows whose token index is
 // >= n_rope are normalised but not rotated (zero-padded tail of the sequence).
-template <int NCH>
+// WEIGHT / ROPE (compile time) say which operands exist; out-of-range chunks and rows that are not
+// rotated load from clamped addresses and discard the value, so the kernel has no branch between
+// its loads and every load is in flight before the first use.
+// WPR waves share one row, as in ln_row.h: chunk i of a lane is 16-byte chunk (i * WPR + wave) * 64 + lane.
+template <int NCH, int WPR, bool WEIGHT, bool ROPE>
 __global__ void __launch_bounds__(256) rmsnorm_rope_kernel(const bf16_t* __restrict__ in, long ldi,
                                                            const bf16_t* __restrict__ weight,
                                                            const float2* __restrict__ rope, int rope_rows,
                                                            bf16_t* __restrict__ out, long ldo, int M, int C,
                                                            int D, float eps, int rows_per_sample,
                                                            int tok_offset, int n_rope, int gh, int gw) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    __shared__ float red[4];
+    int row = blockIdx.x * (4 / WPR) + (threadIdx.x >> 6) / WPR;
+    const bool live = row < M;
+    if constexpr (WPR == 1) {
+        if (!live) return;
+    } else {
+        row = live ? row : M - 1;     // keeps the block's barrier matched; stores nothing
+    }
     const int nchunk = C >> 3;
+    auto chunk = [&](int i) -> int { return (i * WPR + (int)((threadIdx.x >> 6) & (WPR - 1))) * 64 + (int)(threadIdx.x & 63); };
     const uint4* src = reinterpret_cast<const uint4*>(in + (long)row * ldi);
-    uint4 raw[NCH];
+    uint4 raw[NCH], wq[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) raw[i] = src[min(chunk(i), nchunk - 1)];
+    if constexpr (WEIGHT) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) wq[i] = reinterpret_cast<const uint4*>(weight)[min(chunk(i), nchunk - 1)];
+    }
+    const int tok = (row % rows_per_sample) + tok_offset;
+    const bool rotate = ROPE && tok < n_rope;
+    float2 cs[NCH][4];
+    if constexpr (ROPE) {
+        const int t = rotate ? tok : 0;
+        const int pos[3] = {t / gw / gh, (t / gw) % gh, t % gw};
+        const int half = D >> 1;
+        const int n_f = half - 2 * (half / 3), n_h = half / 3;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int col = min(chunk(i), nchunk - 1) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = ((col & (D - 1)) >> 1) + j;   // pair index inside the head
+                const int axis = (p >= n_f) + (p >= n_f + n_h);
+                cs[i][j] = rope[((long)axis * rope_rows + pos[axis]) * half + p];
+            }
+        }
+    }
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int c = i * 64 + lane;
-        raw[i] = make_uint4(0, 0, 0, 0);
-        if (c < nchunk) raw[i] = src[c];
+        if (chunk(i) >= nchunk) raw[i] = make_uint4(0, 0, 0, 0);
         const uint32_t u[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -167,52 +165,31 @@ __global__ void __launch_bounds__(256) rmsnorm_rope_kernel(const bf16_t* __restr
             ss += a * a + b * b;
         }
     }
-    const float rinv = rsqrtf(wave_sum(ss) / (float)C + eps);
-
-    const int tok = (row % rows_per_sample) + tok_offset;
-    const bool rotate = rope != nullptr && tok < n_rope;
-    int pf = 0, ph = 0, pw = 0;
-    if (rotate) {
-        pw = tok % gw;
-        const int t2 = tok / gw;
-        ph = t2 % gh;
-        pf = t2 / gh;
-    }
-    const int half = D >> 1;
-    const int n_f = half - 2 * (half / 3), n_h = half / 3;
+    const float rinv = rsqrtf(row_sum<WPR>(ss, red) / (float)C + eps);
+    if (!live) return;
 
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int c = i * 64 + lane;
-        if (c >= nchunk) continue;
-        const int col = c * 8;
+        const int c = chunk(i);
         const uint32_t u[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
-        uint32_t wu[4] = {0, 0, 0, 0};
-        if (weight) {
-            const uint4 wq = *reinterpret_cast<const uint4*>(weight + col);
-            wu[0] = wq.x; wu[1] = wq.y; wu[2] = wq.z; wu[3] = wq.w;
-        }
+        const uint32_t wu[4] = {wq[i].x, wq[i].y, wq[i].z, wq[i].w};
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float a = bf2f(u[j] & 0xffff), b = bf2f(u[j] >> 16);
-            if (weight) {   // weight == nullptr: rotation only, no normalisation
+            if constexpr (WEIGHT) {   // without a weight: rotation only, no normalisation
                 a = round_bf(round_bf(a * rinv) * bf2f(wu[j] & 0xffff));
                 b = round_bf(round_bf(b * rinv) * bf2f(wu[j] >> 16));
             }
-            if (rotate) {
-                const int p = ((col & (D - 1)) >> 1) + j;   // pair index inside the head
-                const int axis = (p >= n_f) + (p >= n_f + n_h);
-                const int pos = axis == 0 ? pf : (axis == 1 ? ph : pw);
-                const float2 cs = rope[((long)axis * rope_rows + pos) * half + p];
-                const float ra = a * cs.x - b * cs.y;
-                const float rb_ = a * cs.y + b * cs.x;
-                a = ra;
-                b = rb_;
+            if constexpr (ROPE) {
+                const float ra = a * cs[i][j].x - b * cs[i][j].y;
+                const float rb_ = a * cs[i][j].y + b * cs[i][j].x;
+                a = rotate ? ra : a;
+                b = rotate ? rb_ : b;
             }
             o[j] = pack_bf2(a, b);
         }
-        *reinterpret_cast<uint4*>(out + (long)row * ldo + col) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (c < nchunk) *reinterpret_cast<uint4*>(out + (long)row * ldo + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -221,6 +198,7 @@ int ovd_impl_rmsnorm_rope(const bf16_t* in, long ldi, const bf16_t* weight, cons
                           int tok_offset, int n_rope, int gf, int gh, int gw, hipStream_t st) {
     OVD_REQUIRE(C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0, "rmsnorm: C and row strides must be multiples of 8");
     OVD_REQUIRE(rows_per_sample > 0, "rmsnorm: rows_per_sample must be positive");
+    OVD_REQUIRE(weight != nullptr || rope != nullptr, "rmsnorm: neither weight nor rope given");
     if (rope) {
         OVD_REQUIRE(D > 0 && (D & (D - 1)) == 0 && C % D == 0, "rmsnorm: head_dim must be a power of two dividing C");
         OVD_REQUIRE(gf > 0 && gh > 0 && gw > 0 && n_rope <= (long)gf * gh * gw,
@@ -228,19 +206,27 @@ int ovd_impl_rmsnorm_rope(const bf16_t* in, long ldi, const bf16_t* weight, cons
         OVD_REQUIRE(gf <= rope_rows && gh <= rope_rows && gw <= rope_rows, "rmsnorm: rope table too short");
     }
     if (M == 0) return 0;
+    // 16-byte chunks per lane when one wave holds the row; above 4 the row is shared by 2 or 4 waves
     const int nch = ceil_div(C / 8, 64);
-    dim3 grid(ceil_div(M, 4)), blk(256);
-#define RN_CASE(V)                                                                                      \
-    case V:                                                                                             \
-        hipLaunchKernelGGL((rmsnorm_rope_kernel<V>), grid, blk, 0, st, in, ldi, weight,                 \
-                           reinterpret_cast<const float2*>(rope), rope_rows, out, ldo, M, C, D, eps,    \
-                           rows_per_sample, tok_offset, n_rope, gh, gw);                                \
+    OVD_REQUIRE(nch <= 12, "rmsnorm: unsupported width C=%d (at most 6144)", C);
+    const int wpr = nch <= 4 ? 1 : (nch <= 8 ? 2 : 4);
+    dim3 grid(ceil_div(M, 4 / wpr)), blk(256);
+#define RN_LAUNCH(V, P, W, R)                                                                           \
+    hipLaunchKernelGGL((rmsnorm_rope_kernel<V, P, W, R>), grid, blk, 0, st, in, ldi, weight,            \
+                       reinterpret_cast<const float2*>(rope), rope_rows, out, ldo, M, C, D, eps,        \
+                       rows_per_sample, tok_offset, n_rope, gh, gw)
+#define RN_CASE(V, P)                                                                                   \
+    case V * 8 + P:                                                                                     \
+        if (weight && rope) RN_LAUNCH(V, P, true, true);                                                \
+        else if (weight) RN_LAUNCH(V, P, true, false);                                                  \
+        else RN_LAUNCH(V, P, false, true);                                                              \
         break;
-    switch (nch) {
-        RN_CASE(1) RN_CASE(2) RN_CASE(3) RN_CASE(4) RN_CASE(5) RN_CASE(6) RN_CASE(8) RN_CASE(10)
+    switch (ceil_div(nch, wpr) * 8 + wpr) {
+        RN_CASE(1, 1) RN_CASE(2, 1) RN_CASE(3, 1) RN_CASE(4, 1) RN_CASE(3, 2) RN_CASE(4, 2) RN_CASE(3, 4)
         default:
             OVD_FAIL("rmsnorm: unsupported width C=%d", C);
     }
+#undef RN_LAUNCH
 #undef RN_CASE
     OVD_CHECK_LAUNCH("rmsnorm_rope");
     return 0;

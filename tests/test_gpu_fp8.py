@@ -47,8 +47,8 @@ def test_quant_rows_matches_torch_float8(H, M, K):
     assert (err <= 2.0 ** -4 * x.float().abs() + s[:, None] * 2.0 ** -10).all()
 
 
-def test_layernorm_fp8_equals_bf16_kernel_then_quant(H):
-    M, C = 777, 1536
+@pytest.mark.parametrize("M,C", [(777, 1536), (33, 5120), (31, 3072), (5, 512)])
+def test_layernorm_fp8_equals_bf16_kernel_then_quant(H, M, C):
     x = randn((M, C), 2, 2.0) + 0.3
     shift, scale = randn((C,), 3, 0.3), randn((C,), 4, 0.3)
     w, b = (randn((C,), 5, 0.2) + 1).to(BF16), randn((C,), 6, 0.1).to(BF16)

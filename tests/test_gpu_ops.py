@@ -42,7 +42,7 @@ def assert_bf16_close(got, want, ulps=2.0, atol=1e-3, flip_frac=0.0, flip_atol=0
     assert bad.sum() <= flip_frac * bad.numel(), f"{int(bad.sum())}/{bad.numel()} off; max err {err.max():.4g}"
 
 
-@pytest.mark.parametrize("C,M", [(256, 7), (1536, 33), (5120, 5), (4096, 9)])
+@pytest.mark.parametrize("C,M", [(256, 7), (1536, 33), (5120, 5), (4096, 9), (2048, 7), (3072, 13), (768, 2)])
 def test_layernorm_modulate(H, C, M):
     x = syn.randn("ln.x", (M, C), 1, 3.0) + 0.5
     sh, sc = syn.randn("ln.sh", (C,), 1, 0.3), syn.randn("ln.sc", (C,), 1, 0.3)
@@ -56,6 +56,11 @@ def test_layernorm_modulate(H, C, M):
     outb = torch.empty(M, C, device="cuda", dtype=BF16)
     H.layernorm_modulate(dev(x), outb, 1e-6, weight=dev(w, BF16), bias=dev(b, BF16))
     assert_bf16_close(outb, O.layer_norm(x, 1e-6, w, b), ulps=1.01, atol=1e-6)
+    # affine and modulation together, rows with a stride
+    wide = torch.full((M, C + 256), float("nan"), device="cuda")
+    H.layernorm_modulate(dev(x), wide[:, :C], 1e-6, shift=dev(sh), scale=dev(sc), weight=dev(w, BF16), bias=dev(b, BF16))
+    torch.testing.assert_close(wide[:, :C].cpu(), O.layer_norm(x, 1e-6, w, b) * (1 + sc) + sh, rtol=1e-5, atol=1e-5)
+    assert torch.isnan(wide[:, C:]).all()
     # block-0 rounding
     H.layernorm_modulate(dev(x), outb, 1e-6, shift=dev(sh), scale=dev(sc), round_norm=True)
     assert_bf16_close(outb, rb(O.layer_norm(x, 1e-6)) * (1 + sc) + sh, ulps=1.01, atol=1e-6, flip_frac=1e-3,
@@ -316,7 +321,7 @@ def test_attention_tail_balancing_equals_plain_call(H, B, N, L, k_len, copies):
     assert H.flash_attn_workspace_bytes(1, 1024, 2, 1024) == 0 and H.flash_attn_workspace_bytes(2, 75600, 40, 75600) == 0
 
 
-@pytest.mark.parametrize("M,C", [(515, 1536), (100, 5120), (64, 256)])
+@pytest.mark.parametrize("M,C", [(515, 1536), (100, 5120), (64, 256), (101, 3072), (35, 2048)])
 def test_resid_layernorm_equals_gemm_residual_epilogue_then_layernorm(H, M, C):
     """x += y * gate inside the norm kernel == the GEMM's residual epilogue followed by the norm, bit
     for bit, for every output kind."""

@@ -189,15 +189,36 @@ if __name__ == "__main__":
         for K in (128, 256, 512, 1536):
             gemm(40560, 8960, K, 0)
     if "lnres" in args.what:        # LayerNorm-modulate with and without the fused residual update
-        M, C = 40560, 1536
-        x = torch.randn(M, C, device="cuda")
-        y = torch.randn(M, C, device="cuda").to(BF16)
-        sh, sc, gt = (torch.randn(C, device="cuda") * 0.1 for _ in range(3))
-        h = torch.empty(M, C, device="cuda", dtype=BF16)
-        ms = timeit(lambda: H.layernorm_modulate(x, h, 1e-6, shift=sh, scale=sc))
-        print(f"ln_mod {M}x{C}: {ms * 1e3:.1f} us  {M * C * 6 / ms / 1e9:.2f} TB/s")
-        ms = timeit(lambda: H.resid_layernorm_modulate(x, y, h, 1e-6, res_gate=gt, shift=sh, scale=sc))
-        print(f"resid ln_mod {M}x{C}: {ms * 1e3:.1f} us  {M * C * 12 / ms / 1e9:.2f} TB/s")
+        for M, C in ((20480, 1536), (40560, 1536), (75600, 5120)):
+            x = torch.randn(M, C, device="cuda")
+            y = torch.randn(M, C, device="cuda").to(BF16)
+            sh, sc, gt = (torch.randn(C, device="cuda") * 0.1 for _ in range(3))
+            w, b = (torch.randn(C, device="cuda").to(BF16) for _ in range(2))
+            h = torch.empty(M, C, device="cuda", dtype=BF16)
+            ms = timeit(lambda: H.layernorm_modulate(x, h, 1e-6, shift=sh, scale=sc))
+            print(f"ln_mod {M}x{C}: {ms * 1e3:.1f} us  {M * C * 6 / ms / 1e9:.2f} TB/s")
+            ms = timeit(lambda: H.resid_layernorm_modulate(x, y, h, 1e-6, res_gate=gt, shift=sh, scale=sc))
+            print(f"resid ln_mod {M}x{C}: {ms * 1e3:.1f} us  {M * C * 12 / ms / 1e9:.2f} TB/s")
+            ms = timeit(lambda: H.resid_layernorm_modulate(x, y, h, 1e-6, res_gate=gt, weight=w, bias=b))
+            print(f"resid ln affine {M}x{C}: {ms * 1e3:.1f} us  {M * C * 12 / ms / 1e9:.2f} TB/s")
+            h8 = torch.empty(M, C, device="cuda", dtype=torch.uint8)
+            rs = torch.empty(M, device="cuda")
+            ms = timeit(lambda: H.resid_layernorm_modulate(x, y, h8, 1e-6, res_gate=gt, shift=sh, scale=sc, row_scale=rs))
+            print(f"resid ln_mod fp8 {M}x{C}: {ms * 1e3:.1f} us  {M * C * 11 / ms / 1e9:.2f} TB/s")
+            del x, y, h, h8
+        from omnivideo.modules.engine import build_rope_table
+        for M, C, grid in ((20480, 1536, (13, 30, 52)), (75600, 5120, (21, 45, 80))):
+            # q and k of one layer live side by side in the fused QKV output (row stride 3C)
+            qkv = torch.randn(M, 3 * C, device="cuda").to(BF16)
+            wq = torch.randn(C, device="cuda").to(BF16)
+            rope = build_rope_table(128, 1024, qkv.device)
+            o = torch.empty(M, C, device="cuda", dtype=BF16)
+            n = grid[0] * grid[1] * grid[2]
+            ms = timeit(lambda: H.rmsnorm_rope(qkv[:, :C], wq, o, 128, 1e-6, rope=rope, n_rope=n, grid=grid))
+            print(f"rmsnorm_rope {M}x{C}: {ms * 1e3:.1f} us  {M * C * 4 / ms / 1e9:.2f} TB/s")
+            ms = timeit(lambda: H.rmsnorm_rope(qkv[:, :C], wq, o, 128, 1e-6))
+            print(f"rmsnorm {M}x{C}: {ms * 1e3:.1f} us  {M * C * 4 / ms / 1e9:.2f} TB/s")
+            del qkv, o
     if "gemm" in args.what:
         M = 40560
         gemm(M, 4608, 1536, 0)      # fused QKV
