@@ -6,27 +6,30 @@
 // registers), computed transposed (weight rows on the MFMA M axis) so that a lane ends up
 // with 4 consecutive output columns of one row.
 //
-// Operands stream HBM -> LDS with 16-byte global_load_lds into a ring of 4 K-tiles of 32
-// (per K-tile: A part 256 rows x 64 B, W part 256 rows x 64 B = 32 KiB; 128 KiB in all,
-// one workgroup per CU).  A K-tile is consumed in two phases of 16 MFMAs per wave (rows
-// 0-63 then 64-127 of the wave's 128); every phase also puts one 16-KiB part of the
-// K-tile three ahead in flight, so a part has four to five phases to land and the loop
-// never drains the vector-memory counter: one counted s_waitcnt vmcnt(8) per K-tile.
+// Operands stream HBM -> LDS with 16-byte global_load_lds.  K % 64 == 0 (every Linear of the DiT):
+// K-tiles of 32 are staged in PAIRS.  LDS rows are 128 B (64 k-values), so every DMA instruction
+// fetches 8 whole 128-byte lines; the ring holds 2 pairs of 64 KiB (A part 256 rows x 128 B |
+// W part 256 rows x 128 B; one workgroup per CU).  16-byte chunk c of row r sits at chunk position
+// c ^ ((r >> 1) & 7): every 16-lane group of a ds_read_b128 fragment read (either half of the row)
+// hits 16 distinct bank slots.  The swizzle is applied on the SOURCE address of the DMA (its LDS
+// image is lane-linear) and again on the read address.  The even K-tile of a pair puts the whole
+// next pair in flight (8 DMA instructions per wave) into the other slot, the odd one waits for it.
+// Other K (K % 32 == 0): a ring of 4 single K-tiles with 64-byte rows, tile kt + 2 staged during kt.
 //
-// The two waves that share a SIMD (w and w + 4) run half a phase apart: waves 4-7 execute
-// one extra s_barrier before the loop (waves 0-3 one after it), so that one of them issues
-// its LDS reads and DMA while the other one feeds the matrix pipe.
+// A K-tile is one phase per wave: 12 fragment reads, then 32 MFMAs.  The two waves that share a
+// SIMD (w and w + 4) run half a period apart: waves 4-7 execute one extra s_barrier before the loop
+// (waves 0-3 one after it), so that one of them issues its LDS reads and DMA while the other one
+// feeds the matrix pipe.
 //
-// LDS rows are 64 B = 4 chunks of 16 B; chunk c of row r is stored at chunk position
-// c ^ h((r >> 2) & 3), h = {0,3,2,1}, which makes every 16-lane group of a ds_read_b128
-// fragment read hit 16 distinct bank slots.  The swizzle is applied on the SOURCE address
-// of the DMA (its LDS image is lane-linear) and again on the read address.
+// What bounds the loop (measured): the operand stream into the CU.  At 128 FLOP per staged byte the
+// kernel moves ~18 B/clk/CU at 1.25 PFLOP/s; removing half of the DMA (wrong results, timing only)
+// ran at 1.59 PFLOP/s, while a deeper ring (5 tiles), DMA issued from inside the MFMA phase, and one
+// operand staged through registers + ds_write_b128 all ran within 2 % of the plain loop.
 //
 // Hazards the schedule is built around:
-//   * a part is re-staged two phases after its last read (the other half of the waves
-//     reads it half a phase later), and read one phase after the wait that retires it;
-//   * raw s_barrier + explicit lgkmcnt waits only inside the loop: a __syncthreads()
-//     would drain the DMA queue;
+//   * a wave's fragment reads are complete (lgkmcnt(0)) BEFORE the barrier that ends its read
+//     phase, so the slot of the previous pair can be re-staged right behind that barrier;
+//   * raw s_barrier + explicit waits only inside the loop: a __syncthreads() would drain the DMA queue;
 //   * no ordinary global load while DMA is in flight (bias / gate are read in the epilogue).
 #include "common.h"
 
@@ -35,6 +38,7 @@ namespace {
 constexpr int TM = 256, TN = 256, TK = 32, NSTAGE = 4;
 constexpr int PART = 256 * TK * 2;      // 16 KiB: one operand of one K-tile
 constexpr int STAGE = 2 * PART;         // A part | W part
+constexpr int PAIR = 2 * STAGE;         // two K-tiles staged together: A part 32 KiB | W part 32 KiB
 
 enum Epi { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3 };
 
@@ -52,52 +56,8 @@ __device__ __forceinline__ void stage_part(const Src& s, long kbyte, char* dst_w
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-// One K-tile (two phases).  STAGE_NEXT: put K-tile kt + 3 in flight; VMCNT: DMA instructions
-// that may stay outstanding after this tile's wait (8 in the steady state).
-template <bool STAGE_NEXT, int VMCNT>
-__device__ __forceinline__ void k_tile(f32x4 (&acc)[4][8], const char* smem, int kt, const Src& sa, const Src& sw,
-                                       int lane_off, int a_rd, int w_rd, int wave) {
-    const char* st = smem + (kt & (NSTAGE - 1)) * STAGE;
-    char* nx = const_cast<char*>(smem) + ((kt + 3) & (NSTAGE - 1)) * STAGE + wave * 1024;
-    const long kb = (long)(kt + 3) * TK * 2;
-    bf16x8 wf[4], af[4];
-    // ---- phase 0: W fragments + rows 0-63; stage the W part
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wf[t] = lds_frag(st + PART + w_rd + t * 1024 + lane_off);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) af[t] = lds_frag(st + a_rd + t * 1024 + lane_off);
-    if (STAGE_NEXT) stage_part(sw, kb, nx + PART);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 1: rows 64-127; stage the A part; retire the K-tile read next
-#pragma unroll
-    for (int t = 0; t < 4; ++t) af[t] = lds_frag(st + a_rd + (4 + t) * 1024 + lane_off);
-    if (STAGE_NEXT) stage_part(sa, kb, nx);
-    if (VMCNT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    if (VMCNT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    if (VMCNT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            acc[nt][4 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][4 + mt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-}
-
-// One K-tile as a single phase of 32 MFMAs (variant used when PHASES == 1): 12 fragment reads,
-// both parts of K-tile kt + 2 put in flight, one counted wait, two barriers.
+// One K-tile of the single-tile ring: 12 fragment reads, both parts of K-tile kt + 2 put in flight,
+// one counted wait, two barriers.
 template <bool STAGE_NEXT, int VMCNT>
 __device__ __forceinline__ void k_tile1(f32x4 (&acc)[4][8], const char* smem, int kt, const Src& sa, const Src& sw,
                                         int lane_off, int a_rd, int w_rd, int wave) {
@@ -115,8 +75,8 @@ __device__ __forceinline__ void k_tile1(f32x4 (&acc)[4][8], const char* smem, in
     }
     if (VMCNT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (VMCNT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt)
@@ -127,7 +87,49 @@ __device__ __forceinline__ void k_tile1(f32x4 (&acc)[4][8], const char* smem, in
     __builtin_amdgcn_s_barrier();
 }
 
-template <int EPI, int PHASES>
+// ---- paired K-tiles (K % 64 == 0)
+struct Src4 {
+    const char* base;
+    unsigned off[4];       // this lane's byte offsets (clamped row * ld + swizzled chunk) for its four rows
+};
+
+__device__ __forceinline__ void stage_part4(const Src4& s, long kbyte, char* dst_wave) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[i], (lds_ptr)(dst_wave + i * 8192), 16, 0, 0);
+}
+
+// One K-tile (half of the pair in `slot`; lane_off selects the half).  STAGE_NEXT: put the next pair in
+// flight into the other slot; WAIT: retire this wave's share of it.
+template <bool STAGE_NEXT, bool WAIT>
+__device__ __forceinline__ void k_tile2(f32x4 (&acc)[4][8], char* smem, int slot, long kb_next, const Src4& sa,
+                                        const Src4& sw, int lane_off, int a_rd, int w_rd, int wave) {
+    const char* st = smem + slot * PAIR;
+    bf16x8 wf[4], af[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[t] = lds_frag(st + PAIR / 2 + w_rd + t * 2048 + lane_off);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) af[t] = lds_frag(st + a_rd + t * 2048 + lane_off);
+    if (STAGE_NEXT) {
+        char* nx = smem + (slot ^ 1) * PAIR + wave * 1024;
+        stage_part4(sw, kb_next, nx + PAIR / 2);
+        stage_part4(sa, kb_next, nx);
+    }
+    if (WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+// PAIRED: K % 64 == 0, the paired ring; otherwise the ring of single K-tiles.
+template <int EPI, bool PAIRED>
 __global__ void __launch_bounds__(512, 2)
 gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
                const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
@@ -177,24 +179,39 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / TK;      // >= 3 (checked on the host)
     char* const wdst = smem + wave * 1024;
-    if (PHASES == 2) {
+    if (PAIRED) {
+        // staging: wave w, instruction i covers part rows (i*8 + w)*8 .. +7, 8 lanes per 128-byte row
+        Src4 sa4, sw4;
+        sa4.base = sa.base;
+        sw4.base = sw.base;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            stage_part(sw, (long)t * TK * 2, wdst + t * STAGE + PART);
-            stage_part(sa, (long)t * TK * 2, wdst + t * STAGE);
+        for (int i = 0; i < 4; ++i) {
+            const int r = (i * 8 + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            const int ar = min(row0 + r, M - 1);
+            sa4.off[i] = (unsigned)ar * (unsigned)lda * 2u + (unsigned)c * 16u;
+            sw4.off[i] = (unsigned)(col0 + r) * (unsigned)ldw * 2u + (unsigned)c * 16u;
         }
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // K-tile 0 landed (this wave's share)
+        // fragment reads: lane (r = lane & 15, q = lane >> 4) reads chunk 4*half + q of row r of a 16-row block
+        const int lo0 = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4), lo1 = lo0 ^ 64;
+        const int a_rd2 = wr * 16384, w_rd2 = wc * 8192;
+        const int np = K / 64;      // >= 2 (checked on the host)
+        stage_part4(sw4, 0, wdst + PAIR / 2);
+        stage_part4(sa4, 0, wdst);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: half a phase behind
-        int kt = 0;
-        for (; kt < nk - 3; ++kt) k_tile<true, 8>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
-        k_tile<false, 4>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
-        k_tile<false, 0>(acc, smem, kt + 1, sa, sw, lane_off, a_rd, w_rd, wave);
-        k_tile<false, -1>(acc, smem, kt + 2, sa, sw, lane_off, a_rd, w_rd, wave);
+        if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: half a period behind
+        int j = 0;
+        for (; j < np - 1; ++j) {
+            k_tile2<true, false>(acc, smem, j & 1, (long)(j + 1) * 128, sa4, sw4, lo0, a_rd2, w_rd2, wave);
+            k_tile2<false, true>(acc, smem, j & 1, 0, sa4, sw4, lo1, a_rd2, w_rd2, wave);
+        }
+        k_tile2<false, false>(acc, smem, j & 1, 0, sa4, sw4, lo0, a_rd2, w_rd2, wave);
+        k_tile2<false, false>(acc, smem, j & 1, 0, sa4, sw4, lo1, a_rd2, w_rd2, wave);
         if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
     } else {
+        const int nk = K / TK;      // >= 3 (checked on the host)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             stage_part(sw, (long)t * TK * 2, wdst + t * STAGE + PART);
@@ -346,17 +363,18 @@ int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, 
     }
     // 16-byte output stores need 16-byte aligned rows
     const int wide = (ldo % 8 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
-    static int phases = -1;
-    if (phases < 0) {
-        const char* e = getenv("OVD_GEMM_PHASES");
-        phases = (e && atoi(e) == 2) ? 2 : 1;
+    // OVD_GEMM_SINGLE=1 forces the single-tile ring (tuning aid)
+    static int single = -1;
+    if (single < 0) {
+        const char* e = getenv("OVD_GEMM_SINGLE");
+        single = (e && atoi(e) == 1) ? 1 : 0;
     }
-    if (phases == 2) {
-#define PH 2
+    if (K % 64 == 0 && !single) {
+#define PH true
         switch (epilogue) { GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) }
 #undef PH
     } else {
-#define PH 1
+#define PH false
         switch (epilogue) { GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) }
 #undef PH
     }

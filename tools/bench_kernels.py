@@ -219,6 +219,93 @@ if __name__ == "__main__":
             ms = timeit(lambda: H.rmsnorm_rope(qkv[:, :C], wq, o, 128, 1e-6))
             print(f"rmsnorm {M}x{C}: {ms * 1e3:.1f} us  {M * C * 4 / ms / 1e9:.2f} TB/s")
             del qkv, o
+    if "lnrot" in args.what:        # the same kernels on rotating buffers: nothing is left in the 256 MB last-level cache
+        M, C, sets = 20480, 1536, 8
+        xs = [torch.randn(M, C, device="cuda") for _ in range(sets)]
+        ys = [torch.randn(M, C, device="cuda").to(BF16) for _ in range(sets)]
+        hs = [torch.empty(M, C, device="cuda", dtype=BF16) for _ in range(sets)]
+        sh, sc, gt = (torch.randn(C, device="cuda") * 0.1 for _ in range(3))
+        def rot():
+            for x, y, h in zip(xs, ys, hs):
+                H.resid_layernorm_modulate(x, y, h, 1e-6, res_gate=gt, shift=sh, scale=sc)
+        ms = timeit(rot) / sets
+        print(f"resid ln_mod {M}x{C} rotating: {ms * 1e3:.1f} us  {M * C * 12 / ms / 1e9:.2f} TB/s")
+        def rot2():
+            for x, h in zip(xs, hs):
+                H.layernorm_modulate(x, h, 1e-6, shift=sh, scale=sc)
+        ms = timeit(rot2) / sets
+        print(f"ln_mod {M}x{C} rotating: {ms * 1e3:.1f} us  {M * C * 6 / ms / 1e9:.2f} TB/s")
+        def rot3():
+            for y, h in zip(ys, hs):
+                h.copy_(y)
+        ms = timeit(rot3) / sets
+        print(f"torch copy bf16 {M}x{C} rotating: {ms * 1e3:.1f} us  {M * C * 4 / ms / 1e9:.2f} TB/s")
+        def rot4():
+            for i in range(0, sets, 2):
+                xs[i].copy_(xs[i + 1])
+        ms = timeit(rot4) / (sets // 2)
+        print(f"torch copy f32 {M}x{C} rotating: {ms * 1e3:.1f} us  {M * C * 8 / ms / 1e9:.2f} TB/s")
+    if "lnhot" in args.what:        # the rotating LayerNorm right behind a self-attention launch, as in the step
+        M, C, sets = 20480, 1536, 8
+        xs = [torch.randn(M, C, device="cuda") for _ in range(sets)]
+        ys = [torch.randn(M, C, device="cuda").to(BF16) for _ in range(sets)]
+        hs = [torch.empty(M, C, device="cuda", dtype=BF16) for _ in range(sets)]
+        sh, sc, gt = (torch.randn(C, device="cuda") * 0.1 for _ in range(3))
+        q, k, v = (torch.randn(1, 20480, 12, 128, device="cuda").to(BF16) for _ in range(3))
+        o = torch.empty_like(q)
+        for hot in (False, True):
+            tot, n = 0.0, 0
+            for it in range(40):
+                if hot:
+                    H.flash_attn(q, k, v, o, k_len=20280)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for x, y, h in zip(xs, ys, hs):
+                    H.resid_layernorm_modulate(x, y, h, 1e-6, res_gate=gt, shift=sh, scale=sc)
+                e1.record()
+                torch.cuda.synchronize()
+                if it >= 10:
+                    tot += e0.elapsed_time(e1) / sets
+                    n += 1
+            print(f"resid ln_mod rotating, {'behind attention' if hot else 'alone'}: {tot / n * 1e3:.1f} us")
+    if "gemmlib" in args.what:      # the vendor library (torch -> hipBLASLt) on the step's GEMM shapes, for orientation
+        M = 40960
+        for N, K in ((4608, 1536), (1536, 1536), (8960, 1536), (1536, 8960)):
+            a = torch.randn(M, K, device="cuda").to(BF16)
+            w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF16)
+            b = torch.randn(N, device="cuda").to(BF16)
+            out = torch.empty(M, N, device="cuda", dtype=BF16)
+            ms = timeit(lambda: torch.nn.functional.linear(a, w, b))
+            ms2 = timeit(lambda: H.gemm(a, w, out, b, 0))
+            print(f"M{M} N{N} K{K}: library {ms:.3f} ms {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s | "
+                  f"gemm256 {ms2:.3f} ms {2.0 * M * N * K / ms2 / 1e9:.0f} TFLOP/s", flush=True)
+    if "lnseq" in args.what:        # LayerNorm in the step's own surroundings: FFN-up, FFN-down, then the norm
+        M, C, F = 20480, 1536, 8960
+        x = torch.randn(M, C, device="cuda")
+        hb = torch.randn(M, C, device="cuda").to(BF16)
+        ffn = torch.empty(M, F, device="cuda", dtype=BF16)
+        res = torch.empty(M, C, device="cuda", dtype=BF16)
+        w0 = (torch.randn(F, C, device="cuda") / 40).to(BF16)
+        w2 = (torch.randn(C, F, device="cuda") / 90).to(BF16)
+        b0, b2 = torch.zeros(F, device="cuda", dtype=BF16), torch.zeros(C, device="cuda", dtype=BF16)
+        sh, sc, gt = (torch.randn(C, device="cuda") * 0.1 for _ in range(3))
+        for mode in ("ln only", "gemm gemm ln"):
+            tot, n = 0.0, 0
+            for it in range(60):
+                if mode != "ln only":
+                    H.gemm(hb, w0, ffn, b0, H.EPI_BF16_GELU)
+                    H.gemm(ffn, w2, res, b2, H.EPI_BF16)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                H.resid_layernorm_modulate(x, res, hb, 1e-6, res_gate=gt, shift=sh, scale=sc)
+                e1.record()
+                if it % 10 == 9:
+                    torch.cuda.synchronize()
+                if it >= 20:
+                    torch.cuda.synchronize()
+                    tot += e0.elapsed_time(e1)
+                    n += 1
+            print(f"resid ln_mod, {mode}: {tot / n * 1e3:.1f} us (event to event)")
     if "gemm" in args.what:
         M = 40560
         gemm(M, 4608, 1536, 0)      # fused QKV
