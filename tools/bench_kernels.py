@@ -268,6 +268,8 @@ if __name__ == "__main__":
                     tot += e0.elapsed_time(e1) / sets
                     n += 1
             print(f"resid ln_mod rotating, {'behind attention' if hot else 'alone'}: {tot / n * 1e3:.1f} us")
+    if "gemmdown" in args.what:     # one shape for counter passes: FFN-down of the batched step
+        gemm(40960, 1536, 8960, 0)
     if "gemmlib" in args.what:      # the vendor library (torch -> hipBLASLt) on the step's GEMM shapes, for orientation
         M = 40960
         for N, K in ((4608, 1536), (1536, 1536), (8960, 1536), (1536, 8960)):
