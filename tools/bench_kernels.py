@@ -268,6 +268,9 @@ if __name__ == "__main__":
                     tot += e0.elapsed_time(e1) / sets
                     n += 1
             print(f"resid ln_mod rotating, {'behind attention' if hot else 'alone'}: {tot / n * 1e3:.1f} us")
+    if "gemm14" in args.what:       # the A14B step's Linear shapes
+        for N, K, epi in ((15360, 5120, 0), (5120, 5120, 0), (13824, 5120, 1), (5120, 13824, 0)):
+            gemm(75600, N, K, epi)
     if "gemmdown" in args.what:     # one shape for counter passes: FFN-down of the batched step
         gemm(40960, 1536, 8960, 0)
     if "gemmlib" in args.what:      # the vendor library (torch -> hipBLASLt) on the step's GEMM shapes, for orientation
