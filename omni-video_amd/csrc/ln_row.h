@@ -147,6 +147,7 @@ __device__ __forceinline__ bool ln_row(float* __restrict__ x, long ldx, const bf
     return live;
 }
 
-// the (pieces per lane, waves per row) split of a row of C = 256 * n channels, or false
+// instantiated (pieces per lane, waves per row) splits, C = 256 * pieces * waves, and operand flag sets
+// (a gate needs a residual, so LN_GATE never appears without LN_RES)
 #define LN_FOR_EACH_SHAPE(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(6, 1) X(4, 2) X(6, 2) X(4, 4) X(5, 4)
 #define LN_FOR_EACH_FLAGS(X) X(0) X(1) X(3) X(4) X(5) X(7) X(8) X(9) X(11) X(12) X(13) X(15)
