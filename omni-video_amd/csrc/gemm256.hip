@@ -6,15 +6,16 @@
 // registers), computed transposed (weight rows on the MFMA M axis) so that a lane ends up
 // with 4 consecutive output columns of one row.
 //
-// Operands stream HBM -> LDS with 16-byte global_load_lds.  K % 64 == 0 (every Linear of the DiT):
-// K-tiles of 32 are staged in PAIRS.  LDS rows are 128 B (64 k-values), so every DMA instruction
+// Operands stream HBM -> LDS with 16-byte global_load_lds; K-tiles of 32 are staged in PAIRS
+// (K % 64 == 0).  LDS rows are 128 B (64 k-values), so every DMA instruction
 // fetches 8 whole 128-byte lines; the ring holds 2 pairs of 64 KiB (A part 256 rows x 128 B |
 // W part 256 rows x 128 B; one workgroup per CU).  16-byte chunk c of row r sits at chunk position
 // c ^ ((r >> 1) & 7): every 16-lane group of a ds_read_b128 fragment read (either half of the row)
 // hits 16 distinct bank slots.  The swizzle is applied on the SOURCE address of the DMA (its LDS
 // image is lane-linear) and again on the read address.  The even K-tile of a pair puts the whole
 // next pair in flight (8 DMA instructions per wave) into the other slot, the odd one waits for it.
-// Other K (K % 32 == 0): a ring of 4 single K-tiles with 64-byte rows, tile kt + 2 staged during kt.
+// (A ring of 4 single K-tiles with 64-byte rows, half a line per row and DMA instruction, ran 1-4 %
+// slower.)
 //
 // A K-tile is one phase per wave: 12 fragment reads, then 32 MFMAs.  The two waves that share a
 // SIMD (w and w + 4) run half a period apart: waves 4-7 execute one extra s_barrier before the loop
@@ -35,59 +36,16 @@
 
 namespace {
 
-constexpr int TM = 256, TN = 256, TK = 32, NSTAGE = 4;
-constexpr int PART = 256 * TK * 2;      // 16 KiB: one operand of one K-tile
-constexpr int STAGE = 2 * PART;         // A part | W part
-constexpr int PAIR = 2 * STAGE;         // two K-tiles staged together: A part 32 KiB | W part 32 KiB
+constexpr int TM = 256, TN = 256, TK = 32;
+constexpr int PAIR = 2 * 2 * 256 * TK * 2;   // two K-tiles staged together: A part 32 KiB | W part 32 KiB
+constexpr int NPAIR = 2;                     // pairs in the ring
 
 enum Epi { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-struct Src {
-    const char* base;      // operand base advanced to the K-tile being staged (uniform)
-    unsigned off[2];       // this lane's byte offsets (clamped row * ld + swizzled chunk) for its two rows
-};
-
-__device__ __forceinline__ void stage_part(const Src& s, long kbyte, char* dst_wave) {
-    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[0], (lds_ptr)dst_wave, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[1], (lds_ptr)(dst_wave + 8 * 1024), 16, 0, 0);
-}
-
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-// One K-tile of the single-tile ring: 12 fragment reads, both parts of K-tile kt + 2 put in flight,
-// one counted wait, two barriers.
-template <bool STAGE_NEXT, int VMCNT>
-__device__ __forceinline__ void k_tile1(f32x4 (&acc)[4][8], const char* smem, int kt, const Src& sa, const Src& sw,
-                                        int lane_off, int a_rd, int w_rd, int wave) {
-    const char* st = smem + (kt & (NSTAGE - 1)) * STAGE;
-    char* nx = const_cast<char*>(smem) + ((kt + 2) & (NSTAGE - 1)) * STAGE + wave * 1024;
-    const long kb = (long)(kt + 2) * TK * 2;
-    bf16x8 wf[4], af[8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wf[t] = lds_frag(st + PART + w_rd + t * 1024 + lane_off);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) af[t] = lds_frag(st + a_rd + t * 1024 + lane_off);
-    if (STAGE_NEXT) {
-        stage_part(sw, kb, nx + PART);
-        stage_part(sa, kb, nx);
-    }
-    if (VMCNT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    if (VMCNT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-}
-
-// ---- paired K-tiles (K % 64 == 0)
 struct Src4 {
     const char* base;
     unsigned off[4];       // this lane's byte offsets (clamped row * ld + swizzled chunk) for its four rows
@@ -128,8 +86,7 @@ __device__ __forceinline__ void k_tile2(f32x4 (&acc)[4][8], char* smem, int slot
     __builtin_amdgcn_s_barrier();
 }
 
-// PAIRED: K % 64 == 0, the paired ring; otherwise the ring of single K-tiles.
-template <int EPI, bool PAIRED>
+template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
                const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
@@ -155,23 +112,21 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
     const int tn = (bid % per_group) / gsz;
     const int row0 = tm * TM, col0 = tn * TN;
 
-    // staging: wave w, instruction i covers part rows (i*8 + w)*16 .. +15, 4 lanes per row
-    Src sa, sw;
+    // staging: wave w, instruction i covers part rows (i*8 + w)*8 .. +7, 8 lanes per 128-byte row
+    Src4 sa, sw;
     sa.base = reinterpret_cast<const char*>(A);
     sw.base = reinterpret_cast<const char*>(W);
-    {
-        const int c = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = (i * 8 + wave) * 16 + (lane >> 2);
-            const int ar = min(row0 + r, M - 1);
-            sa.off[i] = (unsigned)ar * (unsigned)lda * 2u + (unsigned)c * 16u;
-            sw.off[i] = (unsigned)(col0 + r) * (unsigned)ldw * 2u + (unsigned)c * 16u;
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int ar = min(row0 + r, M - 1);
+        sa.off[i] = (unsigned)ar * (unsigned)lda * 2u + (unsigned)c * 16u;
+        sw.off[i] = (unsigned)(col0 + r) * (unsigned)ldw * 2u + (unsigned)c * 16u;
     }
-    // fragment reads: lane (r = lane & 15, q = lane >> 4) reads chunk q of row r of a 16-row block
-    const int lane_off = (lane & 15) * 64 + (((lane >> 4) ^ ((4 - ((lane & 15) >> 2)) & 3)) << 4);
-    const int a_rd = wr * 8192, w_rd = wc * 4096;
+    // fragment reads: lane (r = lane & 15, q = lane >> 4) reads chunk 4*half + q of row r of a 16-row block
+    const int lo0 = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4), lo1 = lo0 ^ 64;
+    const int a_rd = wr * 16384, w_rd = wc * 8192;
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -180,52 +135,20 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     char* const wdst = smem + wave * 1024;
-    if (PAIRED) {
-        // staging: wave w, instruction i covers part rows (i*8 + w)*8 .. +7, 8 lanes per 128-byte row
-        Src4 sa4, sw4;
-        sa4.base = sa.base;
-        sw4.base = sw.base;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (i * 8 + wave) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            const int ar = min(row0 + r, M - 1);
-            sa4.off[i] = (unsigned)ar * (unsigned)lda * 2u + (unsigned)c * 16u;
-            sw4.off[i] = (unsigned)(col0 + r) * (unsigned)ldw * 2u + (unsigned)c * 16u;
-        }
-        // fragment reads: lane (r = lane & 15, q = lane >> 4) reads chunk 4*half + q of row r of a 16-row block
-        const int lo0 = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4), lo1 = lo0 ^ 64;
-        const int a_rd2 = wr * 16384, w_rd2 = wc * 8192;
-        const int np = K / 64;      // >= 2 (checked on the host)
-        stage_part4(sw4, 0, wdst + PAIR / 2);
-        stage_part4(sa4, 0, wdst);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: half a period behind
-        int j = 0;
-        for (; j < np - 1; ++j) {
-            k_tile2<true, false>(acc, smem, j & 1, (long)(j + 1) * 128, sa4, sw4, lo0, a_rd2, w_rd2, wave);
-            k_tile2<false, true>(acc, smem, j & 1, 0, sa4, sw4, lo1, a_rd2, w_rd2, wave);
-        }
-        k_tile2<false, false>(acc, smem, j & 1, 0, sa4, sw4, lo0, a_rd2, w_rd2, wave);
-        k_tile2<false, false>(acc, smem, j & 1, 0, sa4, sw4, lo1, a_rd2, w_rd2, wave);
-        if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
-    } else {
-        const int nk = K / TK;      // >= 3 (checked on the host)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            stage_part(sw, (long)t * TK * 2, wdst + t * STAGE + PART);
-            stage_part(sa, (long)t * TK * 2, wdst + t * STAGE);
-        }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (wr == 1) __builtin_amdgcn_s_barrier();
-        int kt = 0;
-        for (; kt < nk - 2; ++kt) k_tile1<true, 4>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
-        k_tile1<false, 0>(acc, smem, kt, sa, sw, lane_off, a_rd, w_rd, wave);
-        k_tile1<false, -1>(acc, smem, kt + 1, sa, sw, lane_off, a_rd, w_rd, wave);
-        if (wr == 0) __builtin_amdgcn_s_barrier();
+    const int np = K / 64;      // >= 2 (checked on the host)
+    stage_part4(sw, 0, wdst + PAIR / 2);
+    stage_part4(sa, 0, wdst);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: half a period behind
+    int j = 0;
+    for (; j < np - 1; ++j) {
+        k_tile2<true, false>(acc, smem, j & 1, (long)(j + 1) * 128, sa, sw, lo0, a_rd, w_rd, wave);
+        k_tile2<false, true>(acc, smem, j & 1, 0, sa, sw, lo1, a_rd, w_rd, wave);
     }
+    k_tile2<false, false>(acc, smem, j & 1, 0, sa, sw, lo0, a_rd, w_rd, wave);
+    k_tile2<false, false>(acc, smem, j & 1, 0, sa, sw, lo1, a_rd, w_rd, wave);
+    if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
 
     // epilogue: lane holds out[m][n..n+3], m = row0 + wr*128 + mt*16 + fr, n = col0 + wc*64 + nt*16 + fq*4.
     // Rows outermost: the four stores of a lane for one row are the four 32-byte quarters of
@@ -333,7 +256,7 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
 bool ovd_gemm256_applicable(long lda, long ldw, int M, int N, int K) {
     // one workgroup per CU: worth it from about two rounds of 256 x 256 tiles over the 256 CUs
     const long tiles = (long)ceil_div(M, TM) * (N / TN);
-    return N % TN == 0 && K % TK == 0 && K >= 3 * TK && M >= 2 * TM && tiles >= 512 &&
+    return N % TN == 0 && K % (2 * TK) == 0 && K >= 4 * TK && M >= 2 * TM && tiles >= 512 &&
            (long)M * lda * 2 < (1L << 32) && (long)N * ldw * 2 < (1L << 32);
 }
 
@@ -342,17 +265,17 @@ int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, 
     OVD_REQUIRE(ovd_gemm256_applicable(lda, ldw, M, N, K), "gemm256: shape M=%d N=%d K=%d not supported", M, N, K);
     const int tiles_m = ceil_div(M, TM), tiles_n = N / TN;
     dim3 grid(tiles_m * tiles_n), blk(512);
-    const size_t lds = NSTAGE * STAGE;
+    const size_t lds = NPAIR * PAIR;
 #define GEMM_CASE(E)                                                                                      \
     case E: {                                                                                             \
         static bool attr_set = false;                                                                     \
         if (!attr_set) {                                                                                  \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<E, PH>),                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<E>),                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
                 OVD_FAIL("gemm256: cannot reserve %zu bytes of LDS", lds);                                 \
             attr_set = true;                                                                              \
         }                                                                                                 \
-        hipLaunchKernelGGL((gemm256_kernel<E, PH>), grid, blk, lds, st, A, lda, W, ldw, bias, out, ldo, gate, \
+        hipLaunchKernelGGL((gemm256_kernel<E>), grid, blk, lds, st, A, lda, W, ldw, bias, out, ldo, gate, \
                            M, N, K, tiles_m, tiles_n, gm, wide);                                          \
     } break;
     // tile-rows per group of the tile walk (OVD_GEMM_GM overrides: tuning aid)
@@ -363,21 +286,7 @@ int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, 
     }
     // 16-byte output stores need 16-byte aligned rows
     const int wide = (ldo % 8 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
-    // OVD_GEMM_SINGLE=1 forces the single-tile ring (tuning aid)
-    static int single = -1;
-    if (single < 0) {
-        const char* e = getenv("OVD_GEMM_SINGLE");
-        single = (e && atoi(e) == 1) ? 1 : 0;
-    }
-    if (K % 64 == 0 && !single) {
-#define PH true
-        switch (epilogue) { GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) }
-#undef PH
-    } else {
-#define PH false
-        switch (epilogue) { GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) }
-#undef PH
-    }
+    switch (epilogue) { GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) }
 #undef GEMM_CASE
     OVD_CHECK_LAUNCH("gemm256_bf16");
     return 0;
