@@ -42,31 +42,6 @@
 
 namespace {
 
-// Timing-only ablation (OVD_ATTN_ABLATE_SHAPE at compile time; results are wrong): every 32x32x16
-// MFMA becomes two 16x16x32 MFMAs on the same operand registers and on 8 of the 16 accumulator
-// registers (alternating halves by k-step, so all 16 carry data) - same FLOPs, same LDS reads, same vector work, the other MFMA shape.
-#ifdef OVD_ATTN_ABLATE_SHAPE
-__device__ __forceinline__ f32x16 mfma_shape(bf16x8 a, bf16x8 b, f32x16 c, int sel) {
-    if (sel & 1) {
-        f32x4 lo = {c[8], c[9], c[10], c[11]}, hi = {c[12], c[13], c[14], c[15]};
-        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
-        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, hi, 0, 0, 0);
-        c[8] = lo[0]; c[9] = lo[1]; c[10] = lo[2]; c[11] = lo[3];
-        c[12] = hi[0]; c[13] = hi[1]; c[14] = hi[2]; c[15] = hi[3];
-    } else {
-        f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
-        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
-        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, hi, 0, 0, 0);
-        c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
-        c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
-    }
-    return c;
-}
-#define MFMA_32x32x16(a, b, c, sel) mfma_shape(a, b, c, sel)
-#else
-#define MFMA_32x32x16(a, b, c, sel) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#endif
-
 constexpr int HD = 128;        // head dim
 constexpr int BKV = 64;        // keys per tile
 constexpr int KV_TILE_BYTES = BKV * HD * 2;   // 16 KiB
@@ -219,8 +194,8 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
                 kf[(ks + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(l31, 2 * ks + 2 + hi));
                 kf[(ks + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(32 + l31, 2 * ks + 2 + hi));
             }
-            n0 = MFMA_32x32x16(kf[ks & 1][0], qf[ks], n0, ks);
-            n1 = MFMA_32x32x16(kf[ks & 1][1], qf[ks], n1, ks);
+            n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][0], qf[ks], n0, 0, 0, 0);
+            n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][1], qf[ks], n1, 0, 0, 0);
         }
         const int pi = 3 * (ks >> 1) + 2 * (ks & 1);      // first pair of this k-step: 0,2,3,5,6,8,9,11
         SOFTMAX_PAIR(pi);
@@ -242,7 +217,7 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
             __builtin_bit_cast(bf16x8, make_uint4(pw[4 * st], pw[4 * st + 1], pw[4 * st + 2], pw[4 * st + 3]));
 #pragma unroll
         for (int db = 0; db < 4; ++db)
-            o_acc[db] = MFMA_32x32x16(vf[st & 1][db], pfrag, o_acc[db], st);
+            o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st & 1][db], pfrag, o_acc[db], 0, 0, 0);
         if (st < 2) {
             SOFTMAX_PAIR(12 + 2 * st);
             SOFTMAX_PAIR(13 + 2 * st);
@@ -371,8 +346,8 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
         for (int ks = 0; ks < 8; ++ks) {
             const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(smem + k_off(l31, 2 * ks + hi));
             const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(smem + k_off(32 + l31, 2 * ks + hi));
-            a0 = MFMA_32x32x16(kf0, qf[ks], a0, ks);
-            a1 = MFMA_32x32x16(kf1, qf[ks], a1, ks);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], a1, 0, 0, 0);
         }
         if (nt == 1 && partial) mask_scores<true>(a0, a1, 0, k_len, tail_bias, hi);
         mx = half_max(lane_max32(a0, a1)) * scale_log2;
@@ -469,432 +444,6 @@ ATTN_KERNEL(4)
 ATTN_KERNEL(8)
 #undef ATTN_KERNEL
 
-// =======================================================================================
-// The same pipeline on v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on that shape).
-// Lane (i16 = lane & 15, g = lane >> 4).  S^T sub-tile (key block R of 16, query block Cb of 16):
-// the lane holds 4 scores of query 16*Cb + i16, keys 16*R + 4*g + r; a 64-key tile is 4 x 2
-// sub-tiles, so a lane carries TWO queries (16 scores each) and the row statistics are combined
-// over the four lane groups (v_permlane16_swap + v_permlane32_swap).  For P V the contraction index
-// of a 32-key step runs over the keys in the order the scores already have in a lane,
-//   k = 8*g + j  <->  key 32*c + 16*(j >> 2) + 4*g + (j & 3),
-// on both operands: P^T fragments are the packed scores of sub-tiles (2c, Cb) and (2c + 1, Cb), V^T
-// fragments are two transposed reads 16 key rows apart.  The V image in LDS is swizzled so that those
-// reads (rows 4*g + qd of both lane groups of a half wave) are conflict-free.
-struct Scores16 {
-    f32x4 v[4][2];     // [key block R][query block Cb]
-};
-
-__device__ __forceinline__ int v_off16(int row, int chunk) {
-    return row * 256 + ((chunk ^ ((row & 3) << 2) ^ (((row >> 2) & 1) << 1)) << 4);
-}
-
-// every lane gets the maximum / sum over the four lanes that share its i16 (its query)
-__device__ __forceinline__ float group_max(float x) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __builtin_fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
-}
-__device__ __forceinline__ float group_sum(float x) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
-
-__device__ __forceinline__ float lane_max16(const Scores16& s, int cb) {
-    float mx = max3(s.v[0][cb][0], s.v[0][cb][1], s.v[0][cb][2]);
-    mx = max3(mx, s.v[0][cb][3], s.v[1][cb][0]);
-    mx = max3(mx, s.v[1][cb][1], s.v[1][cb][2]);
-    mx = max3(mx, s.v[1][cb][3], s.v[2][cb][0]);
-    mx = max3(mx, s.v[2][cb][1], s.v[2][cb][2]);
-    mx = max3(mx, s.v[2][cb][3], s.v[3][cb][0]);
-    mx = max3(mx, s.v[3][cb][1], s.v[3][cb][2]);
-    return __builtin_fmaxf(mx, s.v[3][cb][3]);
-}
-
-template <bool MASK>
-__device__ __forceinline__ void mask_scores16(Scores16& s, int key0, int k_len, float tail_bias, int g) {
-    if (MASK) {
-#pragma unroll
-        for (int R = 0; R < 4; ++R)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = key0 + 16 * R + 4 * g + r;
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    if (key == k_len - 1) s.v[R][cb][r] += tail_bias;
-                    if (key >= k_len) s.v[R][cb][r] = -1e30f;
-                }
-            }
-    }
-}
-
-#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-
-// c: scores of the current tile; mx[cb] = their row maxima (scaled, over the lane group), need = some
-// row's maximum outgrew the running one.  n receives the scores of the next tile (HAS_NEXT), read
-// from sk_next; V of the current tile is in sv_cur.
-template <int NW, bool HAS_NEXT, bool MASK_NEXT>
-__device__ __forceinline__ void pipe_step16(f32x4 (&o_acc)[8][2], const bf16x8 (&qf)[2][4], float (&m_c)[2],
-                                            float (&l_run)[2], const Scores16& c, Scores16& n, float (&mx)[2],
-                                            bool& need, const char* sk_next, const char* sv_cur, Stream& ks_,
-                                            char* k_dst, Stream& vs_, char* v_dst, int key0_next, int k_len,
-                                            float tail_bias, float scale_log2, int lane) {
-    const int g = lane >> 4, i16 = lane & 15, qd = i16 >> 2, pp = i16 & 3;
-    if (need) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const float m_new = __builtin_fmaxf(m_c[cb], mx[cb]);
-            const float alpha = __builtin_amdgcn_exp2f(m_c[cb] - m_new);
-            m_c[cb] = m_new;
-            l_run[cb] *= alpha;
-#pragma unroll
-            for (int db = 0; db < 8; ++db)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o_acc[db][cb][j] *= alpha;
-        }
-    }
-    if (HAS_NEXT) {
-#pragma unroll
-        for (int R = 0; R < 4; ++R)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) n.v[R][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    float rs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    uint32_t pw[16];     // packed bf16 pairs of P: word 4*R + 2*cb + h = scores 2h, 2h+1 of sub-tile (R, cb)
-#define SOFTMAX_PAIR16(i)                                                                          \
-    do {                                                                                           \
-        const int R_ = (i) >> 2, cb_ = ((i) >> 1) & 1, h_ = (i) & 1;                               \
-        const float pa_ = __builtin_amdgcn_exp2f(__builtin_fmaf(c.v[R_][cb_][2 * h_], scale_log2, -m_c[cb_]));     \
-        const float pb_ = __builtin_amdgcn_exp2f(__builtin_fmaf(c.v[R_][cb_][2 * h_ + 1], scale_log2, -m_c[cb_])); \
-        rs[cb_][0] += pa_;                                                                         \
-        rs[cb_][1] += pb_;                                                                         \
-        pw[i] = pack_bf2(pa_, pb_);                                                                \
-        asm volatile("" : "+v"(pw[i]), "+v"(rs[cb_][0]), "+v"(rs[cb_][1]));                        \
-    } while (0)
-    bf16x8 vf[2][4];
-    // V^T fragments of PV step st: key step c = st >> 1, d blocks 4*(st & 1) .. +3
-#define READ_V16(st, dst)                                                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                             \
-        const int krow = 32 * ((st) >> 1) + 4 * g + qd;                                            \
-        const int chunk = 2 * (4 * ((st) & 1) + i_) + (pp >> 1);                                   \
-        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                              \
-            (lds_b4_ptr)(sv_cur + v_off16(krow, chunk) + 8 * (pp & 1)));                           \
-        const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                             \
-            (lds_b4_ptr)(sv_cur + v_off16(krow + 16, chunk) + 8 * (pp & 1)));                      \
-        const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi4);     \
-        dst[i_] = __builtin_bit_cast(bf16x8, make_uint4(lo2.x, lo2.y, hi2.x, hi2.y));              \
-    }
-    // S^T of the next tile: step s covers d chunk ks = s >> 1 (32 values) of key blocks 2*(s & 1), +1:
-    // {2 LDS reads, 4 MFMAs on 4 different accumulators, its share of the softmax}
-    bf16x8 kf[2][2];
-    if (HAS_NEXT) {
-        kf[0][0] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(i16, g));
-        kf[0][1] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(16 + i16, g));
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if (HAS_NEXT) {
-            if (s < 7) {
-                const int s1 = s + 1, R1 = 2 * (s1 & 1), c1 = 4 * (s1 >> 1) + g;
-                kf[s1 & 1][0] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(16 * R1 + i16, c1));
-                kf[s1 & 1][1] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(16 * R1 + 16 + i16, c1));
-            }
-            const int R0 = 2 * (s & 1), ks = s >> 1;
-            n.v[R0][0] = MFMA_16x16x32(kf[s & 1][0], qf[0][ks], n.v[R0][0]);
-            n.v[R0][1] = MFMA_16x16x32(kf[s & 1][0], qf[1][ks], n.v[R0][1]);
-            n.v[R0 + 1][0] = MFMA_16x16x32(kf[s & 1][1], qf[0][ks], n.v[R0 + 1][0]);
-            n.v[R0 + 1][1] = MFMA_16x16x32(kf[s & 1][1], qf[1][ks], n.v[R0 + 1][1]);
-        }
-        const int pi = 3 * (s >> 1) + 2 * (s & 1);      // first pair of this step: 0,2,3,5,6,8,9,11
-        SOFTMAX_PAIR16(pi);
-        if (!(s & 1)) SOFTMAX_PAIR16(pi + 1);
-        if (s == 0) stage_next<NW>(ks_, k_dst);
-        if (s == 1) stage_next<NW>(vs_, v_dst);
-        if (s == 7) READ_V16(0, vf[0]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (HAS_NEXT) mask_scores16<MASK_NEXT>(n, key0_next, k_len, tail_bias, g);
-
-    // O^T += V^T P^T of the current tile (step st: key step st >> 1, d blocks 4*(st & 1) .. +3, both
-    // query blocks); beside it the last 8 scores' softmax, then the next tile's lane maxima
-    float nmx[2] = {-3.0e38f, -3.0e38f};
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        if (st < 3) READ_V16(st + 1, vf[(st + 1) & 1]);
-        const int cc = st >> 1;
-        bf16x8 pf[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-            pf[cb] = __builtin_bit_cast(bf16x8, make_uint4(pw[8 * cc + 2 * cb], pw[8 * cc + 2 * cb + 1],
-                                                           pw[8 * cc + 4 + 2 * cb], pw[8 * cc + 4 + 2 * cb + 1]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int db = 4 * (st & 1) + i;
-            o_acc[db][0] = MFMA_16x16x32(vf[st & 1][i], pf[0], o_acc[db][0]);
-            o_acc[db][1] = MFMA_16x16x32(vf[st & 1][i], pf[1], o_acc[db][1]);
-        }
-        if (st < 2) {
-            SOFTMAX_PAIR16(12 + 2 * st);
-            SOFTMAX_PAIR16(13 + 2 * st);
-        } else if (HAS_NEXT) {
-            const int R0 = 2 * (st - 2);
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                nmx[cb] = max3(nmx[cb], n.v[R0][cb][0], n.v[R0][cb][1]);
-                nmx[cb] = max3(nmx[cb], n.v[R0][cb][2], n.v[R0][cb][3]);
-                nmx[cb] = max3(nmx[cb], n.v[R0 + 1][cb][0], n.v[R0 + 1][cb][1]);
-                nmx[cb] = max3(nmx[cb], n.v[R0 + 1][cb][2], n.v[R0 + 1][cb][3]);
-                asm volatile("" : "+v"(nmx[cb]));
-            }
-            if (st == 3) {
-                mx[0] = group_max(nmx[0]) * scale_log2;
-                mx[1] = group_max(nmx[1]) * scale_log2;
-                need = __any(mx[0] > m_c[0] + RESCALE_THR || mx[1] > m_c[1] + RESCALE_THR);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    l_run[0] += rs[0][0] + rs[0][1];
-    l_run[1] += rs[1][0] + rs[1][1];
-#undef READ_V16
-#undef SOFTMAX_PAIR16
-}
-
-constexpr int WS_VALUES16 = 68;    // per lane of a split workgroup: 64 accumulators, 2 row maxima, 2 row sums
-
-template <int NW>
-__device__ __forceinline__ void
-attn_fwd_pipe16(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
-                bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,
-                long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias, int n_qblocks,
-                int n_heads, int n_batch, float* __restrict__ ws, int n_split, int k_split) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2] | V[2]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i16 = lane & 15, g = lane >> 4;
-    // workgroup -> (query block, head, batch) and the tail split: as in attn_fwd_pipe
-    int qb, pair, half = -1, s_idx = 0;
-    {
-        const int id = blockIdx.x, pairs = n_heads * n_batch;
-        if ((pairs & 7) == 0) {
-            int j = id >> 3;
-            const int n_full = (pairs >> 3) * n_qblocks - n_split;
-            if (j >= n_full) {
-                const int h = j - n_full;
-                half = h & 1;
-                s_idx = (id & 7) * n_split + (h >> 1);
-                j = n_full + (h >> 1);
-            }
-            pair = (id & 7) + 8 * (j / n_qblocks);
-            qb = j % n_qblocks;
-        } else {
-            pair = id / n_qblocks;
-            qb = id % n_qblocks;
-        }
-    }
-    const int head = pair % n_heads, b = pair / n_heads;
-    const int q0 = qb * (32 * NW) + wave * 32;
-
-    if (half == 0) {                 // keys [0, k_split): whole tiles, no tail
-        k_len = k_split;
-        tail_bias = 0.f;
-    }
-    const int k_begin = half == 1 ? k_split : 0;
-    if (half == 1) {                 // keys [k_split, k_len)
-        k_len -= k_split;
-        Lk -= k_split;
-    }
-    const bf16_t* Qb = Q + b * q_bs + (long)head * HD;
-    const bf16_t* Kb = K + b * k_bs + (long)head * HD + (long)k_begin * k_ld;
-    const bf16_t* Vb = V + b * v_bs + (long)head * HD + (long)k_begin * v_ld;
-
-    bf16x8 qf[2][4];     // Q^T fragments: query 16*cb + i16, d = 32*ks + 8*g .. +7
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        int qr = q0 + 16 * cb + i16;
-        qr = qr < Lq ? qr : Lq - 1;
-        const bf16_t* qp = Qb + (long)qr * q_ld + 8 * g;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[cb][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
-    }
-    f32x4 o_acc[8][2];   // O^T sub-tiles: d = 16*db + 4*g + r, query 16*cb + i16
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) o_acc[i][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_c[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
-    const int nt = (k_len + BKV - 1) / BKV;
-    const bool partial = nt * BKV > k_len || tail_bias != 0.f;     // last tile needs the fix-up pass
-
-    Stream kst, vst;
-    {
-        const int r = wave * 4 + (lane >> 4), p = lane & 15;
-        kst.base = reinterpret_cast<const char*>(Kb);
-        vst.base = reinterpret_cast<const char*>(Vb);
-        kst.row = (unsigned)r * (unsigned)k_ld * 2u;
-        vst.row = (unsigned)r * (unsigned)v_ld * 2u;
-        kst.chunk = (unsigned)((p ^ (r & 15)) << 4);
-        vst.chunk = (unsigned)((p ^ ((r & 3) << 2) ^ (((r >> 2) & 1) << 1)) << 4);     // v_off16
-        kst.last = (unsigned)(Lk - 1) * (unsigned)k_ld * 2u;
-        vst.last = (unsigned)(Lk - 1) * (unsigned)v_ld * 2u;
-        kst.pass = 4u * NW * (unsigned)k_ld * 2u;
-        vst.pass = 4u * NW * (unsigned)v_ld * 2u;
-        kst.tile = (unsigned)BKV * (unsigned)k_ld * 2u;
-        vst.tile = (unsigned)BKV * (unsigned)v_ld * 2u;
-    }
-    char* const wave_lds = smem + wave * 1024;
-    stage_next<NW>(kst, wave_lds);                                   // K(0) -> K buffer 0
-    stage_next<NW>(vst, wave_lds + 2 * KV_TILE_BYTES);               // V(0) -> V buffer 0
-    stage_next<NW>(kst, wave_lds + KV_TILE_BYTES);                   // K(1) -> K buffer 1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    Scores16 sa, sb;
-    float mx[2];
-    bool need;
-    {   // scores of tile 0
-#pragma unroll
-        for (int R = 0; R < 4; ++R)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) sa.v[R][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int R = 0; R < 4; ++R) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + k_off(16 * R + i16, 4 * ks + g));
-                sa.v[R][0] = MFMA_16x16x32(kf, qf[0][ks], sa.v[R][0]);
-                sa.v[R][1] = MFMA_16x16x32(kf, qf[1][ks], sa.v[R][1]);
-            }
-        if (nt == 1 && partial) mask_scores16<true>(sa, 0, k_len, tail_bias, g);
-        mx[0] = group_max(lane_max16(sa, 0)) * scale_log2;
-        mx[1] = group_max(lane_max16(sa, 1)) * scale_log2;
-        need = __any(mx[0] > m_c[0] + RESCALE_THR || mx[1] > m_c[1] + RESCALE_THR);
-    }
-    __syncthreads();    // every wave is done with K(0) before K(2) overwrites it
-
-#define PIPE_STEP16(HAS_NEXT, MASK_NEXT, C, N, t)                                                        \
-    do {                                                                                                 \
-        const int t_ = (t);                                                                              \
-        pipe_step16<NW, HAS_NEXT, MASK_NEXT>(o_acc, qf, m_c, l_run, C, N, mx, need,                      \
-                                             smem + ((t_ + 1) & 1) * KV_TILE_BYTES,                      \
-                                             smem + (2 + (t_ & 1)) * KV_TILE_BYTES, kst,                 \
-                                             wave_lds + (t_ & 1) * KV_TILE_BYTES, vst,                   \
-                                             wave_lds + (2 + ((t_ + 1) & 1)) * KV_TILE_BYTES,            \
-                                             (t_ + 1) * BKV, k_len, tail_bias, scale_log2, lane);        \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
-        __syncthreads();                                                                                 \
-    } while (0)
-
-    const int n_pipe = partial ? (nt >= 2 ? nt - 2 : 0) : nt - 1;
-    int t = 0;
-    for (; t + 1 < n_pipe; t += 2) {
-        PIPE_STEP16(true, false, sa, sb, t);
-        PIPE_STEP16(true, false, sb, sa, t + 1);
-    }
-    if (t < n_pipe) {
-        PIPE_STEP16(true, false, sa, sb, t);
-        sa = sb;
-        ++t;
-    }
-    if (partial && nt >= 2) {
-        PIPE_STEP16(true, true, sa, sb, t);
-        sa = sb;
-        ++t;
-    }
-    PIPE_STEP16(false, false, sa, sb, t);
-#undef PIPE_STEP16
-
-    if (half >= 0) {                 // partial result in the register layout, [value][lane]: coalesced rows
-        float* w = ws + ((long)(s_idx * 2 + half) * NW + wave) * (WS_VALUES16 * 64) + lane;
-#pragma unroll
-        for (int db = 0; db < 8; ++db)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w[((db * 2 + cb) * 4 + j) * 64] = o_acc[db][cb][j];
-        w[64 * 64] = m_c[0];
-        w[65 * 64] = m_c[1];
-        w[66 * 64] = group_sum(l_run[0]);
-        w[67 * 64] = group_sum(l_run[1]);
-        return;
-    }
-    const float inv[2] = {1.0f / group_sum(l_run[0]), 1.0f / group_sum(l_run[1])};
-    // Output through LDS, [32 rows][256 B] with 16-byte chunk c of row r at c ^ (r & 15), read back a
-    // quarter row per lane (as in attn_fwd_pipe).  A lane writes 4 consecutive d of its two queries per d block.
-    {
-        char* ep = smem + wave * 8192;
-#pragma unroll
-        for (int db = 0; db < 8; ++db)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                uint2 w;
-                w.x = pack_bf2(o_acc[db][cb][0] * inv[cb], o_acc[db][cb][1] * inv[cb]);
-                w.y = pack_bf2(o_acc[db][cb][2] * inv[cb], o_acc[db][cb][3] * inv[cb]);
-                const int row = 16 * cb + i16;
-                *reinterpret_cast<uint2*>(ep + row * 256 + (((2 * db + (g >> 1)) ^ (row & 15)) << 4) + (g & 1) * 8) = w;
-            }
-        const int rr = lane >> 4, cc = lane & 15;
-        bf16_t* ob = O + b * o_bs + (long)head * HD + cc * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = i * 4 + rr;
-            const uint4 w = *reinterpret_cast<const uint4*>(ep + r * 256 + ((cc ^ (r & 15)) << 4));
-            if (q0 + r < Lq) *reinterpret_cast<uint4*>(ob + (long)(q0 + r) * o_ld) = w;
-        }
-    }
-}
-
-#define ATTN16_KERNEL(NW)                                                                                \
-    __global__ void __launch_bounds__(64 * NW, 2) attn16_kernel_w##NW(                                   \
-        const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,       \
-        bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,   \
-        long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias, int n_qblocks,    \
-        int n_heads, int n_batch, float* __restrict__ ws, int n_split, int k_split) {                    \
-        attn_fwd_pipe16<NW>(Q, K, V, O, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs,   \
-                            scale_log2, tail_bias, n_qblocks, n_heads, n_batch, ws, n_split, k_split);   \
-    }
-ATTN16_KERNEL(4)
-ATTN16_KERNEL(8)
-#undef ATTN16_KERNEL
-
-// merge of the two key halves for attn16_kernel (lane roles of that kernel)
-__global__ void __launch_bounds__(64) attn16_merge_kernel(const float* __restrict__ ws, bf16_t* __restrict__ O, int Lq,
-                                                          long o_ld, long o_bs, int n_qblocks, int n_heads,
-                                                          int n_batch, int n_split, int nw) {
-    const int lane = threadIdx.x, i16 = lane & 15, g = lane >> 4;
-    const int s_idx = blockIdx.x / nw, wave = blockIdx.x % nw;
-    const int xcd = s_idx / n_split;
-    const int j = ((n_heads * n_batch) >> 3) * n_qblocks - n_split + s_idx % n_split;
-    const int pair = xcd + 8 * (j / n_qblocks), qb = j % n_qblocks;
-    const int head = pair % n_heads, b = pair / n_heads;
-    const float* w0 = ws + ((long)(s_idx * 2) * nw + wave) * (WS_VALUES16 * 64) + lane;
-    const float* w1 = w0 + (long)nw * (WS_VALUES16 * 64);
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const float m0 = w0[(64 + cb) * 64], m1 = w1[(64 + cb) * 64];
-        const float m = fmaxf(m0, m1);
-        const float a0 = __builtin_amdgcn_exp2f(m0 - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
-        const float inv = 1.0f / (w0[(66 + cb) * 64] * a0 + w1[(66 + cb) * 64] * a1);
-        const int qr = qb * (32 * nw) + wave * 32 + 16 * cb + i16;
-        if (qr >= Lq) continue;
-        bf16_t* op = O + b * o_bs + (long)qr * o_ld + (long)head * HD + 4 * g;
-#pragma unroll
-        for (int db = 0; db < 8; ++db) {
-            float y[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = ((db * 2 + cb) * 4 + i) * 64;
-                y[i] = (w0[r] * a0 + w1[r] * a1) * inv;
-            }
-            uint2 w;
-            w.x = pack_bf2(y[0], y[1]);
-            w.y = pack_bf2(y[2], y[3]);
-            *reinterpret_cast<uint2*>(op + db * 16) = w;
-        }
-    }
-}
-
 // Combines the two key halves of the split query blocks: one 64-lane block per (split block, wave),
 // every lane in the role it had in the attention kernel.  (o, m, l) of a half are relative to its own
 // reference maximum m: o = o0 2^(m0-m) + o1 2^(m1-m), l likewise, out = o / l.
@@ -955,7 +504,7 @@ static int attn_split_plan(int B, int Lq, int N, int k_len) {
 // bytes of workspace with which ovd_impl_attn_fwd can balance its last round (0: it would not split)
 long ovd_impl_attn_workspace_bytes(int B, int Lq, int N, int k_len) {
     if ((long)ceil_div(Lq, 256) * N * B < 256) return 0;
-    return (long)attn_split_plan(B, Lq, N, k_len) * 8 * 2 * 8 * (WS_VALUES16 * 64) * (long)sizeof(float);
+    return (long)attn_split_plan(B, Lq, N, k_len) * 8 * 2 * 8 * (WS_VALUES * 64) * (long)sizeof(float);
 }
 
 // q [B,Lq,N,128], k/v [B,Lk,N,128], out [B,Lq,N,128]; *_ld = elements between
@@ -996,16 +545,10 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
     int n_split = 0, k_split = 0;
     if (waves == 8 && workspace != nullptr) {
         n_split = attn_split_plan(B, Lq, N, k_len);
-        if ((long)n_split * 8 * 2 * 8 * (WS_VALUES16 * 64) * (long)sizeof(float) > workspace_bytes) n_split = 0;
+        if ((long)n_split * 8 * 2 * 8 * (WS_VALUES * 64) * (long)sizeof(float) > workspace_bytes) n_split = 0;
         k_split = (ceil_div(k_len, BKV) / 2) * BKV;
     }
-    // OVD_ATTN_MFMA=16 selects the v_mfma_f32_16x16x32_bf16 kernels (1 % slower as built); default: 32x32x16
-    static int shape32 = -1;
-    if (shape32 < 0) {
-        const char* e = getenv("OVD_ATTN_MFMA");
-        shape32 = (e && atoi(e) == 16) ? 0 : 1;
-    }
-#define ATTN_CASE(KERNEL, MERGE, NW)                                                                            \
+#define ATTN_CASE(KERNEL, NW)                                                                              \
     {                                                                                                      \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
@@ -1021,16 +564,10 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
                            o_ld, q_bs, k_bs, v_bs, o_bs, scale_log2, tail_bias, nqb, N, B,                 \
                            (float*)workspace, n_split, k_split);                                           \
         if (n_split > 0)                                                                                   \
-            hipLaunchKernelGGL(MERGE, dim3(8 * n_split * NW), dim3(64), 0, st,                             \
+            hipLaunchKernelGGL(attn_merge_kernel, dim3(8 * n_split * NW), dim3(64), 0, st,                 \
                                (const float*)workspace, out, Lq, o_ld, o_bs, nqb, N, B, n_split, NW);      \
     }
-    if (shape32) {
-        if (waves == 8) ATTN_CASE(attn_pipe_kernel_w8, attn_merge_kernel, 8)
-        else ATTN_CASE(attn_pipe_kernel_w4, attn_merge_kernel, 4)
-    } else {
-        if (waves == 8) ATTN_CASE(attn16_kernel_w8, attn16_merge_kernel, 8)
-        else ATTN_CASE(attn16_kernel_w4, attn16_merge_kernel, 4)
-    }
+    if (waves == 8) ATTN_CASE(attn_pipe_kernel_w8, 8) else ATTN_CASE(attn_pipe_kernel_w4, 4)
 #undef ATTN_CASE
     OVD_CHECK_LAUNCH("attn_fwd");
     return 0;
