@@ -72,7 +72,9 @@ def test_layernorm_rejects_bad_width(H):
         H.layernorm_modulate(torch.zeros(4, 100, device="cuda"), torch.zeros(4, 100, device="cuda"), 1e-6)
 
 
-@pytest.mark.parametrize("C,N,grid,L", [(256, 2, (3, 4, 6), 80), (1536, 12, (2, 5, 7), 70), (5120, 40, (1, 3, 4), 12)])
+@pytest.mark.parametrize("C,N,grid,L", [(256, 2, (3, 4, 6), 80), (1536, 12, (2, 5, 7), 70), (5120, 40, (1, 3, 4), 12),
+                                          # rows shared by two waves, odd row count; 7 x 64 chunks + a partial one
+                                          (3072, 24, (1, 3, 5), 15), (3840, 30, (1, 2, 3), 7)])
 def test_rmsnorm_rope(H, C, N, grid, L):
     from omnivideo.modules.engine import build_rope_table
     D = C // N
