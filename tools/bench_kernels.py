@@ -271,6 +271,19 @@ if __name__ == "__main__":
     if "gemm14" in args.what:       # the A14B step's Linear shapes
         for N, K, epi in ((15360, 5120, 0), (5120, 5120, 0), (13824, 5120, 1), (5120, 13824, 0)):
             gemm(75600, N, K, epi)
+    if "ffnseq" in args.what:       # FFN-up then FFN-down on the step's buffers: the pair, as the step runs it
+        M, C, F = 40960, 1536, 8960
+        hb = torch.randn(M, C, device="cuda").to(BF16)
+        ffn = torch.empty(M, F, device="cuda", dtype=BF16)
+        res = torch.empty(M, C, device="cuda", dtype=BF16)
+        w0 = (torch.randn(F, C, device="cuda") / 40).to(BF16)
+        w2 = (torch.randn(C, F, device="cuda") / 90).to(BF16)
+        b0, b2 = torch.zeros(F, device="cuda", dtype=BF16), torch.zeros(C, device="cuda", dtype=BF16)
+        def pair():
+            H.gemm(hb, w0, ffn, b0, H.EPI_BF16_GELU)
+            H.gemm(ffn, w2, res, b2, H.EPI_BF16)
+        ms = timeit(pair)
+        print(f"FFN-up + FFN-down M{M}: {ms:.3f} ms  {4.0 * M * C * F / ms / 1e9:.0f} TFLOP/s")
     if "gemmdown" in args.what:     # one shape for counter passes: FFN-down of the batched step
         gemm(40960, 1536, 8960, 0)
     if "gemmlib" in args.what:      # the vendor library (torch -> hipBLASLt) on the step's GEMM shapes, for orientation
