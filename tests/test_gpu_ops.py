@@ -145,6 +145,23 @@ def test_gemm_epilogues(H, M, N, K):
     torch.testing.assert_close(xr.cpu(), x0 + rb(a @ w.t()), rtol=2e-2, atol=2e-2)
 
 
+def test_gemm_large_kernel_is_repeatable(H):
+    """The ring of the 256 x 256 kernel is re-staged right behind a barrier: a staging/read race would
+    show as run-to-run differences (the accumulation order is fixed, so results must be bit-identical)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, N, K = 8192, 4096, 1536
+    a = torch.randn(M, K, device="cuda", generator=g).to(BF16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / 40).to(BF16)
+    b = torch.randn(N, device="cuda", generator=g).to(BF16)
+    first = torch.empty(M, N, device="cuda", dtype=BF16)
+    H.gemm(a, w, first, b, H.EPI_BF16_GELU)
+    out = torch.empty_like(first)
+    for _ in range(20):
+        out.fill_(float("nan"))
+        H.gemm(a, w, out, b, H.EPI_BF16_GELU)
+        assert torch.equal(out, first)
+
+
 def test_gemm_strided_views(H):
     """Writing one third of a fused [M,3C] buffer and reading a strided A."""
     M, C = 70, 256
