@@ -372,6 +372,23 @@ def test_resid_layernorm_equals_gemm_residual_epilogue_then_layernorm(H, M, C):
             assert torch.equal(x, x_ref) and torch.equal(out, ref)
 
 
+def test_flash_attention_is_repeatable(H):
+    """K/V tiles are re-staged by DMA right behind a barrier and the split blocks go through a workspace:
+    a race in either shows as run-to-run differences (every summation order is fixed)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, L, N = 2, 8320, 8          # 2 * 8 * 33 = 528 workgroups of 256 rows: two rounds and a split tail
+    q, k, v = ((torch.randn(B, L, N, 128, device="cuda", generator=g)).to(BF16) for _ in range(3))
+    nbytes = H.flash_attn_workspace_bytes(B, L, N, L - 7)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device="cuda") if nbytes else None
+    first = torch.empty_like(q)
+    H.flash_attn(q, k, v, first, k_len=L - 7, workspace=ws)
+    out = torch.empty_like(q)
+    for _ in range(10):
+        out.fill_(float("nan"))
+        H.flash_attn(q, k, v, out, k_len=L - 7, workspace=ws)
+        assert torch.equal(out, first)
+
+
 def test_reference_signature_flash_attention_lens_scale_dtype():
     """omnivideo.modules.flash_attention (reference attention.py:24-133): per-sample k_lens, full
     q_lens, q_scale, softmax_scale, and the result back in q's dtype."""
