@@ -120,6 +120,20 @@ def test_gemm_fp8_epilogues_vs_dequantised_product(H, M, N, K):
     torch.testing.assert_close(x, x0, rtol=0, atol=1e-5)
 
 
+def test_gemm_fp8_is_repeatable(H):
+    """ring staging / fragment-read races would show as run-to-run differences"""
+    M, N, K = 8192, 4096, 1536
+    a8, sa = H.quant_rows_fp8(randn((M, K), 21).to(BF16))
+    w8, sw = H.quant_rows_fp8(randn((N, K), 22, 1 / math.sqrt(K)).to(BF16))
+    first = torch.empty(M, N, device="cuda", dtype=BF16)
+    H.gemm_fp8(a8, w8, sw, first, None, H.EPI_BF16, a_scale=sa)
+    out = torch.empty_like(first)
+    for _ in range(20):
+        out.fill_(float("nan"))
+        H.gemm_fp8(a8, w8, sw, out, None, H.EPI_BF16, a_scale=sa)
+        assert torch.equal(out, first)
+
+
 def test_gemm_fp8_rejects_unsupported_shapes(H):
     a8 = torch.zeros(64, 128, dtype=torch.uint8, device="cuda")
     sw = torch.ones(256, device="cuda")
