@@ -487,13 +487,7 @@ __global__ void __launch_bounds__(64) attn_merge_kernel(const float* __restrict_
 // Plan of the tail balancing for an 8-wave grid: the number of query blocks per XCD to split in two
 // (0 = none).  Worth it when the last round of workgroups would fill at most half of the CUs.
 static int attn_split_plan(int B, int Lq, int N, int k_len) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = ovd_device_cus();
     const long pairs = (long)B * N, nwg = pairs * ceil_div(Lq, 256);
     if ((pairs & 7) || (cus & 7) || k_len <= 16 * BKV) return 0;      // (at most 1024 keys run on 4-wave workgroups)
     const long rounds = nwg / cus, rem = nwg % cus;
@@ -532,11 +526,8 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
     const float tail_bias = last_key_copies > 1 ? log2f((float)last_key_copies) / scale_log2 : 0.f;
     // 8-wave workgroups (256 query rows) unless that grid would leave compute units idle or the keys are few;
     // OVD_ATTN_WAVES=4|8 overrides (tuning aid)
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("OVD_ATTN_WAVES");
-        forced = e ? atoi(e) : 0;
-    }
+    static std::atomic<int> forced_cache{INT32_MIN};
+    const int forced = ovd_env_int(forced_cache, "OVD_ATTN_WAVES", 0);
     // few keys (cross-attention over a short context): two 4-wave workgroups per CU overlap each other's
     // prologue and epilogue, which is most of such a launch (0.09 vs 0.11 ms at 131 keys; even at ~1500)
     const bool small = (long)ceil_div(Lq, 256) * N * B < 256 || k_len <= 1024;
@@ -550,13 +541,9 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
     }
 #define ATTN_CASE(KERNEL, NW)                                                                              \
     {                                                                                                      \
-        static bool attr_set = false;                                                                      \
-        if (!attr_set) {                                                                                   \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
-                OVD_FAIL("attention: cannot reserve %zu bytes of LDS", lds);                                \
-            attr_set = true;                                                                               \
-        }                                                                                                  \
+        static OvdLdsLimit lim;                                                                            \
+        if (!lim.ensure(reinterpret_cast<const void*>(&KERNEL), lds))                                      \
+            OVD_FAIL("attention: cannot reserve %zu bytes of LDS", lds);                                    \
         const int nqb = ceil_div(Lq, 32 * NW);                                                             \
         OVD_REQUIRE((long)nqb * N * B + 8L * n_split < (1L << 31), "attention: grid too large");           \
         dim3 grid(nqb * N * B + 8 * n_split), blk(64 * NW);                                                \

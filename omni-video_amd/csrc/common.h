@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bit pattern
 
@@ -61,6 +64,54 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- per-device launcher state ----------------------------------------------------
+// Launchers may be called from several host threads at once (ctypes releases the GIL) and for
+// several devices of one process, so what they cache is atomic and keyed by the current device.
+constexpr int OVD_MAX_DEVICES = 64;
+static inline int ovd_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= OVD_MAX_DEVICES) d = 0;
+    return d;
+}
+
+// A kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute):
+// raised on the first launch on each device; repeating the call from a racing thread is harmless.
+struct OvdLdsLimit {
+    std::atomic<size_t> cur[OVD_MAX_DEVICES];
+    bool ensure(const void* fn, size_t bytes) {
+        std::atomic<size_t>& c = cur[ovd_current_device()];
+        size_t old = c.load(std::memory_order_acquire);
+        if (old >= bytes) return true;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+        while (old < bytes && !c.compare_exchange_weak(old, bytes, std::memory_order_release)) {}
+        return true;
+    }
+};
+
+// compute units of the current device (256 on MI355X), looked up once per device
+static inline int ovd_device_cus() {
+    static std::atomic<int> cus[OVD_MAX_DEVICES];
+    const int d = ovd_current_device();
+    int c = cus[d].load(std::memory_order_relaxed);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c <= 0) c = 256;
+        cus[d].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
+// integer tuning switch from the environment, read once per process (`cache` starts at INT32_MIN)
+static inline int ovd_env_int(std::atomic<int>& cache, const char* name, int dflt) {
+    int v = cache.load(std::memory_order_relaxed);
+    if (v == INT32_MIN) {
+        const char* e = getenv(name);
+        v = e ? atoi(e) : dflt;
+        if (v == INT32_MIN) v = dflt;
+        cache.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 
 // Wait states covering the longest MFMA (16 passes) before its results are read by
 // non-MFMA instructions on a path where the compiler's hazard padding may not apply.

@@ -402,13 +402,9 @@ int ovd_impl_gemm_fp8(const uint8_t* A, long lda, const float* a_scale, float a_
     const int wide = (row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
 #define GEMM_CASE(E)                                                                                      \
     case E: {                                                                                             \
-        static bool attr_set = false;                                                                     \
-        if (!attr_set) {                                                                                  \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fp8_kernel<E>),                   \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
-                OVD_FAIL("gemm_fp8: cannot reserve %zu bytes of LDS", lds);                                \
-            attr_set = true;                                                                              \
-        }                                                                                                 \
+        static OvdLdsLimit lim;                                                                           \
+        if (!lim.ensure(reinterpret_cast<const void*>(&gemm_fp8_kernel<E>), lds))                         \
+            OVD_FAIL("gemm_fp8: cannot reserve %zu bytes of LDS", lds);                                    \
         hipLaunchKernelGGL((gemm_fp8_kernel<E>), grid, blk, lds, st, A, lda, a_scale, a_scale_all, W, ldw, \
                            w_scale, bias, out, ldo, gate, out_inv, M, N, K, tiles_m, tiles_n, 4, wide);   \
     } break;

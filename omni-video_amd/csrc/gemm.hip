@@ -177,11 +177,8 @@ int ovd_impl_gemm_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, con
     OVD_REQUIRE(gate == nullptr || epilogue == EPI_RESID, "gemm: gate only applies to the residual epilogue");
     if (M == 0) return 0;
     // large shapes go to the 256 x 256 deep-pipelined kernel (OVD_GEMM256=0 disables: tuning aid)
-    static int use256 = -1;
-    if (use256 < 0) {
-        const char* e = getenv("OVD_GEMM256");
-        use256 = e ? atoi(e) : 1;
-    }
+    static std::atomic<int> use256_cache{INT32_MIN};
+    const int use256 = ovd_env_int(use256_cache, "OVD_GEMM256", 1);
     if (use256 && ovd_gemm256_applicable(lda, ldw, M, N, K))
         return ovd_impl_gemm256_bf16(A, lda, W, ldw, bias, out, ldo, gate, M, N, K, epilogue, st);
     const int tiles_m = ceil_div(M, BM), tiles_n = N / BN;
@@ -189,13 +186,9 @@ int ovd_impl_gemm_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, con
     const size_t lds = 4 * TILE_BYTES;
 #define GEMM_CASE(E)                                                                                      \
     case E: {                                                                                             \
-        static bool attr_set = false;                                                                     \
-        if (!attr_set) {                                                                                  \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<E>),                  \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
-                OVD_FAIL("gemm: cannot reserve %zu bytes of LDS", lds);                                    \
-            attr_set = true;                                                                              \
-        }                                                                                                 \
+        static OvdLdsLimit lim;                                                                           \
+        if (!lim.ensure(reinterpret_cast<const void*>(&gemm_bf16_kernel<E>), lds))                        \
+            OVD_FAIL("gemm: cannot reserve %zu bytes of LDS", lds);                                        \
         hipLaunchKernelGGL((gemm_bf16_kernel<E>), grid, blk, lds, st, A, lda, W, ldw, bias, out, ldo, gate, \
                            M, N, K, tiles_m, tiles_n);                                                    \
     } break;

@@ -268,22 +268,16 @@ int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, 
     const size_t lds = NPAIR * PAIR;
 #define GEMM_CASE(E)                                                                                      \
     case E: {                                                                                             \
-        static bool attr_set = false;                                                                     \
-        if (!attr_set) {                                                                                  \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<E>),                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
-                OVD_FAIL("gemm256: cannot reserve %zu bytes of LDS", lds);                                 \
-            attr_set = true;                                                                              \
-        }                                                                                                 \
+        static OvdLdsLimit lim;                                                                           \
+        if (!lim.ensure(reinterpret_cast<const void*>(&gemm256_kernel<E>), lds))                          \
+            OVD_FAIL("gemm256: cannot reserve %zu bytes of LDS", lds);                                     \
         hipLaunchKernelGGL((gemm256_kernel<E>), grid, blk, lds, st, A, lda, W, ldw, bias, out, ldo, gate, \
                            M, N, K, tiles_m, tiles_n, gm, wide);                                          \
     } break;
     // tile-rows per group of the tile walk (OVD_GEMM_GM overrides: tuning aid)
-    static int gm = -1;
-    if (gm < 0) {
-        const char* e = getenv("OVD_GEMM_GM");
-        gm = (e && atoi(e) > 0) ? atoi(e) : 4;
-    }
+    static std::atomic<int> gm_cache{INT32_MIN};
+    int gm = ovd_env_int(gm_cache, "OVD_GEMM_GM", 4);
+    if (gm <= 0) gm = 4;
     // 16-byte output stores need 16-byte aligned rows
     const int wide = (ldo % 8 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
     switch (epilogue) { GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) }

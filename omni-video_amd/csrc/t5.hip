@@ -131,13 +131,9 @@ int ovd_impl_t5_attention(const bf16_t* qkv, long ld, const bf16_t* pos, const i
                 "t5 attention: bad row strides");
     const size_t lds = (size_t)(QROWS * L + QROWS * T5_HD) * sizeof(float);
     OVD_REQUIRE(lds <= 160 * 1024, "t5 attention: L=%d too long for one LDS score tile", L);
-    static size_t cur = 0;
-    if (lds > cur) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&t5_attn_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            OVD_FAIL("t5 attention: cannot reserve %zu bytes of LDS", lds);
-        cur = lds;
-    }
+    static OvdLdsLimit lim;
+    if (!lim.ensure(reinterpret_cast<const void*>(&t5_attn_kernel), lds))
+        OVD_FAIL("t5 attention: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL(t5_attn_kernel, dim3(ceil_div(L, QROWS), N, B), dim3(256), lds, st, qkv, ld, pos, bucket,
                        k_lens, out, ldo, L, N);
     OVD_CHECK_LAUNCH("t5_attention");

@@ -401,39 +401,23 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
     }
     // few voxels (the latent-resolution layers: one 60 x 104 frame per chunk): 32-channel workgroups
     // instead, so that the grid covers the chip at least twice (same arithmetic per output element)
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = ovd_device_cus();
     if (nb > 1 && (long)tiles * ceil_div(Cout, 32 * nb) < 2L * cus) nb = 1;
     {   // OVD_VAE_NB=1|2|3|4 forces the width where it divides Cout (tuning aid)
-        static int forced = -1;
-        if (forced < 0) {
-            const char* e = getenv("OVD_VAE_NB");
-            forced = e ? atoi(e) : 0;
-        }
+        static std::atomic<int> forced_cache{INT32_MIN};
+        const int forced = ovd_env_int(forced_cache, "OVD_VAE_NB", 0);
         if (forced >= 1 && forced <= 4 && Cout % (32 * forced) == 0) nb = forced;
     }
     const size_t lds = (size_t)(HR * WR + 2 * 32 * nb) * LDV * sizeof(float);
     dim3 grid(tiles, ceil_div(Cout, 32 * nb)), blk(256);
     // split-bf16 products by default; OVD_VAE_EXACT_FP32=1 selects the exact fp32 matrix path
-    static int exact = -1;
-    if (exact < 0) {
-        const char* e = getenv("OVD_VAE_EXACT_FP32");
-        exact = (e && atoi(e) != 0) ? 1 : 0;
-    }
+    static std::atomic<int> exact_cache{INT32_MIN};
+    const int exact = ovd_env_int(exact_cache, "OVD_VAE_EXACT_FP32", 0) != 0 ? 1 : 0;
 #define CONV_CASE(NBV, SPL)                                                                                    \
     case NBV: {                                                                                                \
-        static size_t cur = 0;                                                                                 \
-        if (lds > cur) {                                                                                       \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_cl_kernel<NBV, SPL>),                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)       \
-                OVD_FAIL("conv3d: cannot reserve %zu bytes of LDS", lds);                                      \
-            cur = lds;                                                                                         \
-        }                                                                                                      \
+        static OvdLdsLimit lim;                                                                                \
+        if (!lim.ensure(reinterpret_cast<const void*>(&conv3d_cl_kernel<NBV, SPL>), lds))                      \
+            OVD_FAIL("conv3d: cannot reserve %zu bytes of LDS", lds);                                          \
         hipLaunchKernelGGL((conv3d_cl_kernel<NBV, SPL>), grid, blk, lds, st, a);                               \
     } break;
     OVD_REQUIRE(w != nullptr || (w_split != nullptr && !exact),
