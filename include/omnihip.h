@@ -120,6 +120,21 @@ int ovd_flash_attn_ws_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint1
                                int64_t o_bs, float softmax_scale, void* workspace, int64_t workspace_bytes,
                                void* stream);
 
+/* ovd_flash_attn_ws_fwd_bf16 without the workspace argument, for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the
+ * tail-balancing workspace is a 33 MiB (34 603 008 byte) device array inside the library, which every
+ * GPU the library runs on holds until the process ends.  No counterpart in the reference.  The call
+ * allocates and frees nothing; results are bit-identical to ovd_flash_attn_ws_fwd_bf16 given a
+ * workspace of ovd_flash_attn_workspace_bytes(...) bytes.  A shape whose split needs more than the
+ * array holds is rejected (return 1, reason in ovd_last_error()); the array covers every shape on a
+ * 256-CU device.  The first call on each device looks the array's device address up (one
+ * hipGetSymbolAddress): make it outside graph capture.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two streams, two host threads) race on it; calls on one stream do not. */
+int ovd_flash_attn_static_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, int B,
+                                   int Lq, int Lk, int N, int head_dim, int k_len, int last_key_copies,
+                                   int64_t q_ld, int64_t k_ld, int64_t v_ld, int64_t o_ld, int64_t q_bs,
+                                   int64_t k_bs, int64_t v_bs, int64_t o_bs, float softmax_scale, void* stream);
+
 /* [Cin,T,H,W] (fp32, or bf16 when lat_is_bf16) -> bf16 rows [f*h*w, Cin*pt*ph*pw] in
  * (f,h,w) token order and (cin,pt,ph,pw) column order, ready for ovd_gemm_bf16 against
  * the flattened Conv3d weight.  Replaces the im2col half of nn.Conv3d with

@@ -24,6 +24,8 @@ int ovd_impl_gemm_bf16(const bf16_t*, long, const bf16_t*, long, const bf16_t*, 
 int ovd_impl_attn_fwd(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, long, long,
                       long, long, long, long, long, long, float, int, void*, long, hipStream_t);
 long ovd_impl_attn_workspace_bytes(int, int, int, int);
+int ovd_impl_attn_fwd_static(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, long,
+                             long, long, long, long, long, long, long, float, int, hipStream_t);
 int ovd_impl_to_uint8(const float*, uint8_t*, long, long, int, long, float, float, hipStream_t);
 int ovd_impl_resize_coeffs(int, int, int*, int*, int);
 int ovd_impl_quant_rows_fp8(const bf16_t*, long, uint8_t*, long, float*, int, int, hipStream_t);
@@ -134,6 +136,15 @@ int ovd_flash_attn_ws_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint1
                 "attention: workspace_bytes=%lld without a workspace", (long long)workspace_bytes);
     return ovd_impl_attn_fwd(q, k, v, out, B, Lq, Lk, N, head_dim, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs,
                              o_bs, softmax_scale, last_key_copies, workspace, workspace_bytes, ST(stream));
+}
+
+int ovd_flash_attn_static_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, int B,
+                                   int Lq, int Lk, int N, int head_dim, int k_len, int last_key_copies, int64_t q_ld,
+                                   int64_t k_ld, int64_t v_ld, int64_t o_ld, int64_t q_bs, int64_t k_bs,
+                                   int64_t v_bs, int64_t o_bs, float softmax_scale, void* stream) {
+    NONNULL(q); NONNULL(k); NONNULL(v); NONNULL(out);
+    return ovd_impl_attn_fwd_static(q, k, v, out, B, Lq, Lk, N, head_dim, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs,
+                                    v_bs, o_bs, softmax_scale, last_key_copies, ST(stream));
 }
 
 int ovd_patchify(const void* lat, int lat_is_bf16, uint16_t* rows, int Cin, int T, int H, int W, int pt, int ph,

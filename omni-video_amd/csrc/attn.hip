@@ -501,6 +501,50 @@ long ovd_impl_attn_workspace_bytes(int B, int Lq, int N, int k_len) {
     return (long)attn_split_plan(B, Lq, N, k_len) * 8 * 2 * 8 * (WS_VALUES * 64) * (long)sizeof(float);
 }
 
+int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Lq, int Lk,
+                      int N, int D, int k_len, long q_ld, long k_ld, long v_ld, long o_ld, long q_bs, long k_bs,
+                      long v_bs, long o_bs, float softmax_scale, int last_key_copies, void* workspace,
+                      long workspace_bytes, hipStream_t st);
+
+// ---- allocation-free variant ------------------------------------------------------------------
+// The tail-balancing workspace as a device array of the library itself, for callers that cannot
+// allocate.  Sized for the largest split the plan above produces on a 256-CU device: 16 query blocks
+// per XCD x 8 XCDs x 2 key halves x 8 waves x 66 values x 64 lanes x 4 bytes = 33 MiB, held by every
+// device the library runs on until the process ends.  Each device has its own copy at its own
+// address; `scratch` itself is only a host-side handle for hipGetSymbolAddress.
+constexpr long ATTN_SCRATCH_BYTES = 16L * 8 * 2 * 8 * (WS_VALUES * 64) * (long)sizeof(float);
+static __device__ __align__(256) unsigned char scratch[ATTN_SCRATCH_BYTES];
+
+int ovd_impl_attn_fwd_static(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Lq, int Lk,
+                             int N, int D, int k_len, long q_ld, long k_ld, long v_ld, long o_ld, long q_bs,
+                             long k_bs, long v_bs, long o_bs, float softmax_scale, int last_key_copies,
+                             hipStream_t st) {
+    static std::atomic<void*> dev_ptr[OVD_MAX_DEVICES];      // device address of `scratch`, per device
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OVD_MAX_DEVICES)
+        OVD_FAIL("attention (static workspace): no current device, or device index %d beyond %d", dev,
+                 OVD_MAX_DEVICES - 1);
+    void* ptr = dev_ptr[dev].load(std::memory_order_acquire);
+    if (ptr == nullptr) {       // first call on this device (with it current): look the array up once
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || ptr == nullptr)
+            OVD_FAIL("attention (static workspace): hipGetSymbolAddress failed on device %d: %s", dev,
+                     hipGetErrorString(e));
+        dev_ptr[dev].store(ptr, std::memory_order_release);
+    }
+    OVD_REQUIRE(B > 0 && N > 0 && Lq > 0 && k_len > 0, "attention: empty problem B=%d N=%d Lq=%d k_len=%d", B, N, Lq,
+                k_len);
+    const long need = ovd_impl_attn_workspace_bytes(B, Lq, N, k_len);
+    OVD_REQUIRE(need <= ATTN_SCRATCH_BYTES,
+                "attention (static workspace): B=%d Lq=%d N=%d k_len=%d needs %ld bytes of split workspace, the "
+                "built-in array holds %ld; use ovd_flash_attn_ws_fwd_bf16 with a caller-owned workspace",
+                B, Lq, N, k_len, need, ATTN_SCRATCH_BYTES);
+    // every value of the workspace is written by the split workgroups before the merge kernel reads it:
+    // nothing has to start at zero, and the previous call's contents are simply overwritten
+    return ovd_impl_attn_fwd(q, k, v, out, B, Lq, Lk, N, D, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs,
+                             softmax_scale, last_key_copies, ptr, ATTN_SCRATCH_BYTES, st);
+}
+
 // q [B,Lq,N,128], k/v [B,Lk,N,128], out [B,Lq,N,128]; *_ld = elements between
 // consecutive tokens, *_bs = elements between batch entries (so the fused QKV
 // projection buffer can be addressed in place).  Keys at index >= k_len are masked; key

@@ -24,6 +24,8 @@ SIGNATURES = {
     "ovd_flash_attn_ws_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p,
                                    _l, _p],
     "ovd_flash_attn_workspace_bytes": [_i, _i, _i, _i],
+    "ovd_flash_attn_static_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f,
+                                       _p],
     "ovd_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_time_sinusoid": [_p, _p, _i, _p, _i, _p],
     "ovd_gemv_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -198,12 +200,14 @@ def flash_attn_workspace_bytes(B, Lq, N, k_len):
     return int(lib().ovd_flash_attn_workspace_bytes(int(B), int(Lq), int(N), int(k_len)))
 
 
-def flash_attn(q, k, v, out, k_len=None, softmax_scale=None, last_key_copies=1, workspace=None):
+def flash_attn(q, k, v, out, k_len=None, softmax_scale=None, last_key_copies=1, workspace=None,
+               static_workspace=False):
     """q [B,Lq,N,D], k/v [B,Lk,N,D], out [B,Lq,N,D] bf16; the (N,D) dims must be dense, the
     token and batch dims may be strided (views into a fused projection buffer).  Keys at or
     beyond k_len are masked; key k_len - 1 counts last_key_copies times (a run of identical
     trailing keys folded into one).  workspace: a device byte buffer of
-    flash_attn_workspace_bytes(...) bytes (optional; see the header)."""
+    flash_attn_workspace_bytes(...) bytes (optional; see the header); static_workspace=True uses
+    the library's built-in array instead (the allocation-free entry point)."""
     B, Lq, N, D = q.shape
     Lk = k.shape[1]
     for t in (q, k, v, out):
@@ -213,6 +217,13 @@ def flash_attn(q, k, v, out, k_len=None, softmax_scale=None, last_key_copies=1, 
         raise ValueError("attention: shape mismatch")
     scale = float(softmax_scale) if softmax_scale is not None else D ** -0.5
     kl = int(Lk if k_len is None else k_len)
+    if static_workspace:
+        if workspace is not None:
+            raise ValueError("attention: pass either a workspace or static_workspace=True")
+        _call("ovd_flash_attn_static_fwd_bf16", _ptr(q, BF16), _ptr(k, BF16), _ptr(v, BF16), _ptr(out, BF16), B, Lq,
+              Lk, N, D, kl, int(last_key_copies), q.stride(1), k.stride(1), v.stride(1), out.stride(1), q.stride(0),
+              k.stride(0), v.stride(0), out.stride(0), scale, _stream())
+        return out
     if workspace is not None:
         if not workspace.is_cuda or not workspace.is_contiguous():
             raise ValueError("attention: workspace must be a contiguous device tensor")
