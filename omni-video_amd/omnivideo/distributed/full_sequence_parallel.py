@@ -6,7 +6,7 @@ setting `.sp_group` on each (reference x2x_gen_unified.py:172-182)."""
 import torch
 
 from .. import _hip as H
-from ..modules.engine import TorchGroupComm, build_rope_table
+from ..modules.engine import build_rope_table, make_group_comm
 from .ulysses import distributed_attention
 from .util import get_rank, get_world_size
 
@@ -20,7 +20,7 @@ def sp_dit_forward(self, x, t, context, seq_len, y=None):
     group = getattr(self, "sp_group", None)
     comm = getattr(self, "_sp_comm", None)
     if comm is None or comm.group is not group:
-        comm = TorchGroupComm(group) if get_world_size(group) > 1 else None
+        comm = make_group_comm(group) if get_world_size(group) > 1 else None
         self._sp_comm = comm
     return self._forward_impl(x, t, context, seq_len, y=y, comm=comm)
 

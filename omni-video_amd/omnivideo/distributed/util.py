@@ -81,6 +81,17 @@ def get_world_size(group=None):
     return dist.get_world_size(group=group)
 
 
+def _resolve(group):
+    return _SEQUENCE_PARALLEL_GROUP if group is None else group
+
+
+def _host_only(group):
+    """gloo moves host memory only: device tensors are staged through the host (rehearsals of the
+    multi-rank path by several processes on one GPU; RCCL takes device tensors directly)."""
+    from .host_staged import moves_host_memory_only
+    return moves_host_memory_only(_resolve(group))
+
+
 def all_to_all(x, scatter_dim, gather_dim, group=None, **kwargs):
     """Scatter x along `scatter_dim`, gather along `gather_dim` (reference util.py:95-121).
     Inference only: no autograd function is attached."""
@@ -91,7 +102,11 @@ def all_to_all(x, scatter_dim, gather_dim, group=None, **kwargs):
         raise ValueError(f"dim {scatter_dim} of size {x.size(scatter_dim)} is not divisible by {world} ranks")
     send = torch.stack([u for u in x.chunk(world, dim=scatter_dim)]).contiguous()
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
+    if send.is_cuda and _host_only(group):
+        from .host_staged import HostStagedComm
+        HostStagedComm(_resolve(group)).all_to_all(recv, send)
+    else:
+        dist.all_to_all_single(recv, send, group=_resolve(group))
     return torch.cat(list(recv.unbind(0)), dim=gather_dim).contiguous()
 
 
@@ -100,9 +115,10 @@ def all_gather(tensor, group=None):
     world = get_world_size(group)
     if world == 1:
         return [tensor]
-    out = torch.empty(world * tensor.numel(), dtype=tensor.dtype, device=tensor.device)
-    dist.all_gather_into_tensor(out, tensor.contiguous().view(-1), group=group)
-    return list(out.view((world,) + tuple(tensor.shape)).unbind(0))
+    dev = torch.device("cpu") if tensor.is_cuda and _host_only(group) else tensor.device
+    out = torch.empty(world * tensor.numel(), dtype=tensor.dtype, device=dev)
+    dist.all_gather_into_tensor(out, tensor.contiguous().view(-1).to(dev), group=_resolve(group))
+    return list(out.to(tensor.device).view((world,) + tuple(tensor.shape)).unbind(0))
 
 
 def gather_forward(input, dim, group=None):

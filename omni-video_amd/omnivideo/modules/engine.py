@@ -117,6 +117,14 @@ class TorchGroupComm:
         return torch.cat([p[:, :n] for p, n in zip(parts, rows)], dim=1)
 
 
+def make_group_comm(group=None):
+    """The communicator for a sequence-parallel process group: RCCL collectives on device tensors
+    ("nccl" backend), or the host-staged equivalent when the group's backend only moves host memory
+    (gloo: several ranks rehearsing on one GPU)."""
+    from ..distributed.host_staged import HostStagedComm, moves_host_memory_only
+    return HostStagedComm(group) if moves_host_memory_only(group) else TorchGroupComm(group)
+
+
 FP8_LINEARS = ("qkv", "o", "cq", "co", "f0", "f2")
 
 

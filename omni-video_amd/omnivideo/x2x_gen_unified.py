@@ -69,21 +69,43 @@ class DenoiseLoop:
         self.sched.step_cfg(self.out[0], self.out[1], self.guide, self.lat, step_ptr=self.step_ptr)
         H.step_advance(self.step_ptr)
 
-    def step_once(self, i):
-        key = id(self.models_by_step[i])
+    def _snapshot(self):
+        st = self.state
+        bufs = [self.lat, self.step_ptr] + [st[k] for k in ("last", "m1", "m2") if k in st]
+        return [(b, b.clone()) for b in bufs]
+
+    def prepare(self):
+        """Captures the step graph of every expert now (instead of at each expert's first step): one
+        eager step to warm lazy initialisation, then the capture.  The latents, the sampler history and
+        the step counter are restored afterwards, so the run that follows is unaffected."""
         if not self.use_graph:
+            return
+        for key in self.engines:
+            if key in self.graphs:
+                continue
+            saved = self._snapshot()
             self._step(key)
-        elif key in self.graphs:
-            self.graphs[key].replay()
-        else:
-            # one eager step warms every lazy initialisation, then the same launch sequence
-            # is captured (capture records, it does not execute) and replayed from then on
-            self._step(key)
+            for b, c in saved:
+                b.copy_(c)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(g):
                 self._step(key)
             self.graphs[key] = g
+
+    def seek(self, i):
+        """Continue from step i of the schedule (the device-side step counter follows)."""
+        self.done = int(i)
+        self.step_ptr.fill_(int(i))
+
+    def step_once(self, i):
+        key = id(self.models_by_step[i])
+        if not self.use_graph:
+            self._step(key)
+            return
+        if key not in self.graphs:
+            self.prepare()
+        self.graphs[key].replay()
 
     def run(self, num_steps=None):
         """Runs the next `num_steps` steps (default: all that remain)."""
@@ -153,8 +175,8 @@ class OmniVideoX2XUnified:
             self.sp_group = init_sequence_parallel_group(self.config.get("sp_size", 1) if sp_size is None else sp_size)
             self.sp_size = get_sequence_parallel_size()
             self.sp_rank = get_rank(self.sp_group)
-            from .modules.engine import TorchGroupComm
-            self.sp_comm = TorchGroupComm(self.sp_group) if self.sp_size > 1 else None
+            from .modules.engine import make_group_comm
+            self.sp_comm = make_group_comm(self.sp_group) if self.sp_size > 1 else None
         else:
             self.sp_group, self.sp_size, self.sp_rank, self.sp_comm = None, 1, 0, None
 

@@ -1,0 +1,80 @@
+"""One sequence-parallel rank of tests/test_gpu_sp_processes.py: a fresh process on cuda:0.  Several
+ranks share the one GPU of the test box, so the process group runs on gloo and the product picks its
+host-staged communicator (RCCL refuses two ranks on one device); everything else - group creation,
+method binding, row sharding, RoPE offsets, head scatter, context broadcast, row-sharded VAE decode -
+is the code a multi-GPU run executes.  Results go to <outdir>/rank<r>.pt for the parent to compare."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "omni-video_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import _sp_case as case                              # noqa: E402
+
+
+def case_generate(outdir, rank, world):
+    pipe, cfg = case.build_pipeline(use_usp=True, sp_size=world, rank=rank)
+    assert pipe.sp_size == world and pipe.sp_comm is not None
+    wm = pipe.high_noise_model.wan_model
+    assert wm.forward.__func__.__name__ == "sp_dit_forward"
+    assert wm.blocks[0].self_attn.forward.__func__.__name__ == "sp_attn_forward"
+    assert wm.blocks[0].cross_attn.forward.__func__.__name__ == "sp_cross_attn_forward"
+    lat, video = case.run_generate(pipe, cfg)
+    # the model-level entry the pipeline binds (sp_dit_forward): every rank gets the full output
+    kw = case.generate_inputs(cfg)
+    t = torch.tensor([640.0], device="cuda")
+    y = wm(kw["noise"].cuda()[None].unbind(0), t, [kw["precomputed_context"].cuda()], 72)[0]
+    torch.cuda.synchronize()
+    torch.save(dict(lat=None if lat is None else lat.cpu(), video=None if video is None else video.cpu(),
+                    dit=y.cpu()), os.path.join(outdir, f"rank{rank}.pt"))
+
+
+def case_attention(outdir, rank, world):
+    """sp_attn_forward / sp_cross_attn_forward / distributed_attention on this rank's row shard."""
+    import types
+    from omnivideo.distributed import util as U
+    from omnivideo.distributed.full_sequence_parallel import sp_attn_forward, sp_cross_attn_forward
+    from omnivideo.distributed.ulysses import distributed_attention
+    from omnivideo.modules.attention import flash_attention
+    pipe, cfg = case.build_pipeline(use_usp=False)
+    group = U.init_sequence_parallel_group(world)
+    blk = pipe.high_noise_model.wan_model.blocks[1]
+    x, ctx, grid, seq_lens = case.attention_inputs(cfg)
+    B, L, C = x.shape
+    s, sc = L // world, ctx.shape[1] // world
+    N, D = blk.self_attn.num_heads, blk.self_attn.head_dim
+    res = {}
+    for m in (blk.self_attn, blk.cross_attn):
+        m.sp_group = group
+    sa = types.MethodType(sp_attn_forward, blk.self_attn)
+    ca = types.MethodType(sp_cross_attn_forward, blk.cross_attn)
+    res["self"] = sa(x[:, rank * s:(rank + 1) * s].contiguous(), seq_lens, grid).cpu()
+    res["cross"] = ca(x[:, rank * s:(rank + 1) * s].contiguous(), ctx[:, rank * sc:(rank + 1) * sc].contiguous(),
+                      None).cpu()
+    q, k, v = (t.view(B, L, N, D) for t in (x, x.flip(1).contiguous(), (x * 0.5).contiguous()))
+    sl = slice(rank * s, (rank + 1) * s)
+    res["ulysses"] = distributed_attention(q[:, sl].contiguous(), k[:, sl].contiguous(), v[:, sl].contiguous(),
+                                           seq_lens, sp_group=group).cpu()
+    res["ulysses_ref_rows"] = flash_attention(q, k, v, k_lens=seq_lens)[:, sl].cpu()
+    torch.cuda.synchronize()
+    torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
+
+
+def main():
+    which, outdir = sys.argv[1], sys.argv[2]
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="env://")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    with torch.no_grad():
+        {"generate": case_generate, "attention": case_attention}[which](outdir, rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} ok")
+
+
+if __name__ == "__main__":
+    main()
