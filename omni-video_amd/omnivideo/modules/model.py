@@ -228,6 +228,32 @@ class Head(nn.Module):
         self.head = nn.Linear(dim, math.prod(patch_size) * out_dim)
         self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
 
+    def forward(self, x, e):
+        """x [B, L, C], e fp32 [B, L, C] or [B, 1, C] with the same row for every token of a sample
+        (the timestep embedding) -> fp32 [B, L, prod(patch_size) * out_dim] (reference model.py:278-290):
+        fp32 LayerNorm, 2-way modulation and the projection in exact fp32 on the matrix cores."""
+        assert e.dtype == F32
+        B, L, C = x.shape
+        pt, ph, pw = self.patch_size
+        xf = x.to(F32).contiguous()
+        e = e.to(x.device)
+        hmod = torch.empty(2, C, dtype=F32, device=x.device)
+        y = torch.empty(L, C, dtype=F32, device=x.device)
+        tmp = torch.empty(self.out_dim, L * pt, ph, pw, dtype=F32, device=x.device)
+        outs = []
+        for b in range(B):
+            eb = e[b]
+            if eb.shape[0] > 1 and not bool((eb == eb[:1]).all()):
+                raise NotImplementedError("Head: a different modulation row per token is not built "
+                                          "(the model passes one timestep embedding per sample)")
+            H.head_modulation(self.modulation.data.reshape(2, C), eb[0].contiguous(), hmod)
+            H.layernorm_modulate(xf[b], y, self.eps, shift=hmod[0], scale=hmod[1])
+            # the fused projection writes token l's (p, q, r, c) outputs to tmp[c, l*pt + p, q, r]
+            H.head_unpatchify(y, self.head.weight.data, self.head.bias.data, tmp, (L, 1, 1), self.patch_size,
+                              self.out_dim)
+            outs.append(tmp.view(self.out_dim, L, pt, ph, pw).permute(1, 2, 3, 4, 0).reshape(L, -1).clone())
+        return torch.stack(outs)
+
 
 class WanModel(nn.Module):
     """reference model.py:293-549.  `forward` keeps the reference signature; the work is
@@ -302,8 +328,14 @@ class WanModel(nn.Module):
             assert y is not None
         if y is not None:
             x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]
-        if t.dim() != 1:
-            raise NotImplementedError("per-token timesteps are not built: the pipeline passes one t per sample")
+        if t.dim() == 2:
+            # [B, L]: the reference broadcasts one timestep per sample over the tokens
+            # (model.py:467-476); every token of a sample must carry the same value
+            if not bool((t == t[:, :1]).all()):
+                raise NotImplementedError("timesteps that differ between the tokens of a sample are not built")
+            t = t[:, 0]
+        elif t.dim() != 1:
+            raise ValueError(f"t must have shape [B] or [B, L], got {tuple(t.shape)}")
         eng = self.engine()
         outs = []
         tt = t.to(eng.device, torch.float64).contiguous()
@@ -322,7 +354,17 @@ class WanModel(nn.Module):
         return outs
 
     def unpatchify(self, x, grid_sizes):
-        raise NotImplementedError("unpatchify is fused into ovd_head_unpatchify")
+        """List of [L, prod(patch_size) * Cout] head outputs -> list of [Cout, F, H, W] (reference
+        model.py:526-549).  A layout change only; the forward does not come through here (the head
+        kernel scatters its result directly, ovd_head_unpatchify)."""
+        c = self.out_dim
+        out = []
+        for u, v in zip(x, grid_sizes.tolist() if torch.is_tensor(grid_sizes) else grid_sizes):
+            f, h, w = (int(i) for i in v)
+            pt, ph, pw = self.patch_size
+            u = u[:f * h * w].view(f, h, w, pt, ph, pw, c).permute(6, 0, 3, 1, 4, 2, 5)
+            out.append(u.reshape(c, f * pt, h * ph, w * pw))
+        return out
 
     def init_weights(self):
         """reference model.py:551-573"""

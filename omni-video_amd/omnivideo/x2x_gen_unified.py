@@ -212,11 +212,28 @@ class OmniVideoX2XUnified:
         self.low_noise_model = self._new_model(wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len)
 
     def _load_special_tokens(self, checkpoint_dir):
-        path = os.path.join(checkpoint_dir, "special_tokens.pkl") if checkpoint_dir else None
-        if not path or not os.path.exists(path):
+        """The delimiter-token embeddings (reference :215-226).  The reference unpickles
+        `special_tokens.pkl`; unpickling executes code from the file, so here the dictionary is read
+        with a loader that executes nothing: `special_tokens.pt` (a `torch.save` of the same dict) if
+        present, else `special_tokens.pkl` if it happens to be a torch archive.  A raw pickle is
+        refused with the one-line conversion its owner has to run once."""
+        if not checkpoint_dir:
             return None
-        toks = torch.load(path, map_location="cpu", weights_only=True)
-        assert isinstance(toks, dict), "special_tokens should be a dictionary"
+        pt, pkl = (os.path.join(checkpoint_dir, n) for n in ("special_tokens.pt", "special_tokens.pkl"))
+        path = pt if os.path.exists(pt) else pkl if os.path.exists(pkl) else None
+        if path is None:
+            return None
+        try:
+            toks = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as err:      # raw pickle: "Invalid magic number" / unsupported global
+            raise RuntimeError(
+                f"{path} is not a torch.save archive that loads with weights_only=True ({type(err).__name__}: "
+                f"{str(err).splitlines()[0][:120]}).  This build does not unpickle checkpoint files.  Re-save "
+                "the dictionary once, in an environment you trust the file in: "
+                "python -c \"import pickle, torch; torch.save(pickle.load(open('special_tokens.pkl','rb')), "
+                "'special_tokens.pt')\" - special_tokens.pt is looked for first.") from err
+        if not isinstance(toks, dict):
+            raise TypeError("special_tokens should be a dictionary")
         return {k: v.to(self.param_dtype).to(self.device) for k, v in toks.items()}
 
     def _prepare_model_for_timestep(self, t, boundary, offload_model=False):

@@ -252,6 +252,63 @@ def wan_forward(lat, t, ctx, seq_len, sd, cfg, flow="fp32", num_layers=None, pre
     return head_unpatchify(x, e, sd, cfg, grid, pre)
 
 
+def wan_forward_rows(lat, t, ctx, seq_len, sd, cfg, rows, flow="fp32", pre="wan_model."):
+    """wan_forward for a ONE-layer model, evaluated only at the token rows `rows`: returns the head
+    output [len(rows), pt*ph*pw*Cout] of those tokens (column order (p, q, r, c) as in
+    head_unpatchify), i.e. the latent patch each token writes.  Every operator of the forward is
+    row-local except self-attention, whose keys and values are needed for all tokens; with one
+    layer those come straight from the patch embedding, so the cost is one K/V projection over the
+    sequence plus |rows| rows of everything else.  Used where a whole forward is out of reach for the
+    CPU (75 600 tokens at width 5120).  Same arithmetic, line by line, as wan_forward."""
+    assert cfg["num_layers"] == 1
+    eps, N = cfg["eps"], cfg["num_heads"]
+    rows = torch.as_tensor(rows, dtype=torch.long)
+    x, grid = patch_embed(rb(lat, flow), sd[pre + "patch_embedding.weight"],
+                          sd[pre + "patch_embedding.bias"], cfg["patch_size"], flow)
+    n_valid = x.shape[0]
+    x = torch.cat([x, x.new_zeros(seq_len - n_valid, x.shape[1])])
+    e, e0 = time_embed(t, sd, cfg, pre)
+    c = text_embed(rb(ctx, flow), sd, cfg, flow, pre)
+    angles = rope_angles(cfg["dim"] // cfg["num_heads"], grid)
+    bp = f"{pre}blocks.0"
+    D = cfg["dim"] // N
+    mod = sd[bp + ".modulation"].reshape(6, -1) + e0
+    n1 = layer_norm(x, eps)
+    if flow == "bf16":
+        n1 = rb(n1, flow)
+    h = n1 * (1 + mod[1]) + mod[0]
+    sp = bp + ".self_attn"
+    k = rope_rotate(rms_norm(linear(h, sd, sp + ".k", flow), sd[sp + ".norm_k.weight"], eps, flow).view(-1, N, D), angles)
+    v = linear(h, sd, sp + ".v", flow).view(-1, N, D)
+    q = rms_norm(linear(h[rows], sd, sp + ".q", flow), sd[sp + ".norm_q.weight"], eps, flow).view(-1, N, D)
+    # RoPE of the sampled rows: rope_rotate rotates row i by angles[i], so hand it the rows' own angles
+    ang_r = torch.zeros(len(rows), angles.shape[1], dtype=angles.dtype)
+    real = rows < angles.shape[0]
+    ang_r[real] = angles[rows[real]]
+    q = rope_rotate(q, ang_r)                 # a zero angle is the identity: padded rows stay unrotated
+    a = attention(q, k, v, k_len=n_valid, flow=flow)
+    xr = x[rows] + linear(a.reshape(len(rows), -1), sd, sp + ".o", flow) * mod[2]
+    n3 = layer_norm(xr, eps, sd[bp + ".norm3.weight"], sd[bp + ".norm3.bias"])
+    kv = cross_kv(c, sd, bp + ".cross_attn", eps, flow)
+    xr = xr + cross_attention(n3, kv, sd, bp + ".cross_attn", N, eps, flow)
+    hh = layer_norm(xr, eps) * (1 + mod[4]) + mod[3]
+    hh = rb(gelu_tanh(linear(hh, sd, bp + ".ffn.0", flow)), flow)
+    xr = xr + linear(hh, sd, bp + ".ffn.2", flow) * mod[5]
+    m = sd[pre + "head.modulation"].reshape(2, -1) + e[None, :]
+    y = layer_norm(xr, eps) * (1 + m[1]) + m[0]
+    return F.linear(y, sd[pre + "head.head.weight"], sd[pre + "head.head.bias"])
+
+
+def gather_token_patches(out, rows, grid, patch):
+    """The [len(rows), pt*ph*pw*Cout] patches that tokens `rows` own in an unpatchified
+    [Cout, F, H, W] output (inverse of the scatter in head_unpatchify)."""
+    f, h, w = grid
+    pt, ph, pw = patch
+    c = out.shape[0]
+    u = out.reshape(c, f, pt, h, ph, w, pw).permute(1, 3, 5, 2, 4, 6, 0).reshape(f * h * w, pt * ph * pw * c)
+    return u[torch.as_tensor(rows, dtype=torch.long)]
+
+
 # ---------------------------------------------------------------- condition builder
 
 def vlm_project(ar, sd, cfg, flow):

@@ -13,6 +13,8 @@ import math
 import pytest
 import torch
 
+from conftest import check_rel
+
 from omnivideo.utils import synthetic as syn
 from oracle import dit as O
 
@@ -167,7 +169,7 @@ def test_one_block_full_width_full_length_vs_oracle():
     sdb = O.round_weights_bf16(sd)
     ref = O.wan_forward(lat.float(), 640, ctxs[0].float(), L, sdb, cfg, "bf16")
     rel = float((out[0].cpu() - ref).norm() / ref.norm())
-    assert rel < 1.5e-2, rel
+    check_rel("1.3B block, full grid, vs bf16 oracle", rel, 2e-4)      # observed 6.2e-5
 
 
 def test_vae_decode_full_size_causality():
@@ -206,4 +208,5 @@ def test_full_depth_1p3b_forward_at_cpu_reference_case_shape():
     torch.cuda.synchronize()
     ref = O.wan_forward(lat.float(), 875, ctx.float(), 1280, O.round_weights_bf16(sd), cfg, "bf16")
     rel = float((out.cpu() - ref).norm() / ref.norm())
-    assert torch.isfinite(out).all() and rel < 3e-2, rel
+    assert torch.isfinite(out).all()
+    check_rel("1.3B 30 layers at cfg1 shape vs bf16 oracle", rel, 1.5e-3)      # observed 4.1e-4

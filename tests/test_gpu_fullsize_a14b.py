@@ -1,0 +1,242 @@
+"""Parity at the A14B geometry (81 frames 1280x720: 75 600 tokens per guidance branch, 151 200 rows in
+the batch of two; width 5120, 40 heads, FFN 13 824 - reference configs/wan_t2v_A14B.py:19-42).
+
+Operands here are 2-5 GB, close to or past the 4 GiB limit of 32-bit byte offsets, so addressing is
+what these tests are after.  As at the 1.3B size, kernels are checked on sampled output rows (a
+sampled row is computed in full by the oracle: a GEMM / norm row depends on its own input row, an
+attention row on its query and all keys), through exact properties (truncation == masking, bitwise),
+and one whole transformer block of the real width runs on the full token grid against the oracle's
+sampled-row forward (oracle.dit.wan_forward_rows, pinned to the whole forward in
+tests/test_oracle_dit.py)."""
+import math
+
+import pytest
+import torch
+
+from conftest import check_rel
+
+from omnivideo.utils import synthetic as syn
+from oracle import dit as O
+
+pytestmark = pytest.mark.gpu
+BF16, F32, F8 = torch.bfloat16, torch.float32, torch.float8_e4m3fn
+L, NB, N, D, C, FF = 75600, 2, 40, 128, 5120, 13824
+GRID = (21, 45, 80)
+M = NB * L
+
+
+@pytest.fixture(scope="module")
+def H():
+    import omnivideo._hip as H
+    H.lib()
+    return H
+
+
+def close(got, want, ulps=2.0, atol=1e-3, flip_frac=0.0, flip_atol=0.0):
+    got, want = got.float().cpu(), want.float().cpu()
+    err = (got - want).abs()
+    tol = atol + ulps * 2.0 ** -8 * want.abs()
+    bad = err > tol
+    assert not (err > tol + flip_atol).any(), f"max err {err.max():.4g}"
+    assert bad.sum() <= flip_frac * bad.numel(), f"{int(bad.sum())}/{bad.numel()} off"
+
+
+def gpu_randn(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(BF16)
+
+
+def sample_rows(n, total, seed, edges=()):
+    r = torch.randint(0, total, (n,), generator=torch.Generator().manual_seed(seed))
+    return torch.cat([torch.tensor(list(edges), dtype=torch.long), r])
+
+
+EDGES_M = (0, 255, 256, M // 2 - 1, M // 2, M - 257, M - 256, M - 1)
+
+
+@pytest.mark.parametrize("Nout,K,name", [(3 * C, C, "qkv"), (C, C, "o"), (FF, C, "ffn0"), (C, FF, "ffn2")])
+def test_gemm_bf16_a14b_shapes_sampled_rows(H, Nout, K, name):
+    a = gpu_randn((M, K), 21)
+    w = gpu_randn((Nout, K), 22, 1 / math.sqrt(K))
+    bias = gpu_randn((Nout,), 23, 0.1)
+    rows = sample_rows(88, M, 8, EDGES_M)
+    acc = a[rows].float().cpu() @ w.float().cpu().t() + bias.float().cpu()
+    out = torch.empty(M, Nout, device="cuda", dtype=BF16)
+    H.gemm(a, w, out, bias, H.EPI_BF16)
+    close(out[rows], acc, ulps=1.01, atol=2e-4)
+    H.gemm(a, w, out, bias, H.EPI_BF16_GELU)
+    close(out[rows], O.gelu_tanh(acc.to(BF16).float()), ulps=2.01, atol=2e-3, flip_frac=2e-4, flip_atol=4e-2)
+    del out
+    g = torch.Generator(device="cuda").manual_seed(24)
+    gate = torch.randn(Nout, device="cuda", generator=g)
+    x = torch.empty(M, Nout, device="cuda")
+    H.gemm(a, w, x, bias, H.EPI_F32)
+    close(x[rows], acc, ulps=1.01, atol=2e-4)
+    assert torch.equal(x[rows].to(BF16).float(), x[rows])            # fp32 holding the bf16-rounded value
+    x.fill_(0.25)
+    H.gemm(a, w, x, bias, H.EPI_RESID, gate=gate)
+    want = 0.25 + acc.to(BF16).float() * gate.cpu()
+    torch.testing.assert_close(x[rows].cpu(), want, rtol=2e-2, atol=2e-2)
+    H.gemm(a, w, x, bias, H.EPI_RESID, gate=-gate)             # adds exactly one update per element
+    torch.testing.assert_close(x[rows].cpu(), torch.full_like(want, 0.25), rtol=0, atol=1e-5)
+
+
+def test_gemm_bf16_operand_past_4gib_takes_the_64bit_kernel(H):
+    """The 256x256 kernel stages operands with 32-bit byte offsets and is only chosen for operands
+    below 4 GiB.  FFN-down at this geometry is 4.18 GB (2.6 % under); with a row stride of 14 336
+    elements the same matrix spans 4.34 GB and must come out right through the other kernel."""
+    K, ld = FF, 14336
+    assert M * K * 2 < 2 ** 32 <= M * ld * 2
+    buf = torch.empty(M, ld, device="cuda", dtype=BF16)
+    g = torch.Generator(device="cuda").manual_seed(31)
+    for r0 in range(0, M, 37800):                           # fill in slabs: no 9 GB fp32 temporary
+        buf[r0:r0 + 37800] = torch.randn(37800, ld, device="cuda", generator=g).to(BF16)
+    a = buf[:, :K]
+    w = gpu_randn((C, K), 32, 1 / math.sqrt(K))
+    rows = sample_rows(56, M, 9, EDGES_M)
+    acc = a[rows].float().cpu() @ w.float().cpu().t()
+    out = torch.empty(M, C, device="cuda", dtype=BF16)
+    H.gemm(a, w, out, None, H.EPI_BF16)
+    close(out[rows], acc, ulps=1.01, atol=2e-4)
+    # and the same values through the contiguous (below 4 GiB, 256x256 kernel) layout: bitwise equal
+    out2 = torch.empty_like(out)
+    H.gemm(a.contiguous(), w, out2, None, H.EPI_BF16)
+    close(out2[rows], acc, ulps=1.01, atol=2e-4)
+
+
+@pytest.mark.parametrize("Nout,K,name", [(3 * C, C, "qkv"), (C, C, "o"), (FF, C, "ffn0"), (C, FF, "ffn2")])
+def test_gemm_fp8_a14b_shapes_sampled_rows(H, Nout, K, name):
+    a = gpu_randn((M, K), 41)
+    w = gpu_randn((Nout, K), 42, 1 / math.sqrt(K))
+    bias = gpu_randn((Nout,), 43, 0.1)
+    a8, sa = H.quant_rows_fp8(a)
+    w8, sw = H.quant_rows_fp8(w)
+    rows = sample_rows(56, M, 10, EDGES_M)
+    # row quantisation at this size: sampled rows against torch's float8 conversion
+    ar = a[rows].float().cpu()
+    mx = ar.abs().amax(dim=1)
+    s_ref = torch.where(mx > 0, mx / 448.0, torch.ones_like(mx))
+    assert torch.equal(sa[rows].cpu(), s_ref)
+    assert torch.equal(a8[rows].cpu(), (ar * (1.0 / s_ref)[:, None]).clamp(-448, 448).to(F8).view(torch.uint8))
+    del a
+    acc = ((a8[rows].view(F8).float().cpu() * sa[rows].cpu()[:, None]).double()
+           @ (w8.view(F8).float().cpu() * sw.cpu()[:, None]).double().t()).float() + bias.float().cpu()
+    out = torch.empty(M, Nout, device="cuda", dtype=BF16)
+    H.gemm_fp8(a8, w8, sw, out, bias, H.EPI_BF16, a_scale=sa)
+    close(out[rows], acc, ulps=1.01, atol=3e-4)
+    g8 = torch.empty(M, Nout, device="cuda", dtype=torch.uint8)
+    H.gemm_fp8(a8, w8, sw, out, bias, H.EPI_BF16_GELU, a_scale=sa)
+    H.gemm_fp8(a8, w8, sw, g8, bias, H.EPI_FP8_GELU, a_scale=sa, out_scale=0.25)
+    assert torch.equal(g8[rows], (out[rows].float() * 4.0).clamp(-448, 448).to(F8).view(torch.uint8))
+    del g8, out
+    x = torch.full((M, Nout), 0.25, device="cuda")
+    gate = torch.randn(Nout, device="cuda", generator=torch.Generator(device="cuda").manual_seed(44))
+    H.gemm_fp8(a8, w8, sw, x, bias, H.EPI_RESID, a_scale=sa, gate=gate)
+    torch.testing.assert_close(x[rows].cpu(), 0.25 + acc.to(BF16).float() * gate.cpu(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("heads", [40, 5])
+def test_self_attention_a14b_length_in_place_qkv(H, heads):
+    """75 600 tokens, all 40 heads (one GPU) and 5 heads (the share of one of 8 sequence-parallel ranks),
+    q/k/v read in place from the fused projection buffer (token stride 3*N*128: the K/V slab of a batch
+    entry spans 2.3 GB), batch of two guidance branches."""
+    Cq = heads * D
+    qkv = torch.empty(NB, L, 3 * Cq, device="cuda", dtype=BF16)
+    g = torch.Generator(device="cuda").manual_seed(51)
+    for b in range(NB):
+        qkv[b] = torch.randn(L, 3 * Cq, device="cuda", generator=g).to(BF16)
+    q, k, v = (qkv[:, :, i * Cq:(i + 1) * Cq].unflatten(2, (heads, D)) for i in range(3))
+    ws = torch.empty(max(H.flash_attn_workspace_bytes(NB, L, heads, L), 1), dtype=torch.uint8, device="cuda")
+    out = torch.full((NB, L, heads, D), float("nan"), device="cuda", dtype=BF16)
+    H.flash_attn(q, k, v, out, workspace=ws)
+    assert torch.isfinite(out.float()).all()
+    rows = sample_rows(55, L, 5, (0, 1, 31, 32, 255, 256, L - 257, L - 2, L - 1))
+    for b in ((1,) if heads == 40 else (0, 1)):
+        ref = O.attention(q[b, rows].float().cpu(), k[b].float().cpu(), v[b].float().cpu(), flow="fp32")
+        close(out[b, rows], ref, ulps=2.0, atol=6e-3)
+    if heads == 5:
+        # masking the key tail == handing over truncated K/V, bit for bit; and the plain entry point
+        # (no tail balancing) differs from the workspace one by fp32 summation order at most
+        kl = 60001
+        o1, o2 = torch.empty_like(out), torch.empty_like(out)
+        H.flash_attn(q, k, v, o1, k_len=kl)
+        H.flash_attn(q, k[:, :kl].contiguous(), v[:, :kl].contiguous(), o2)
+        assert torch.equal(o1, o2)
+        H.flash_attn(q, k, v, o1)
+        close(o1, out, ulps=2.0, atol=6e-3)
+
+
+def test_norm_kernels_a14b_rows(H):
+    """The 4-waves-per-row variants (C = 5120) over all 151 200 rows, sampled rows against the oracle."""
+    from omnivideo.modules.engine import build_rope_table
+    g = torch.Generator(device="cuda").manual_seed(61)
+    x = torch.empty(M, C, device="cuda")
+    for r0 in range(0, M, 37800):
+        x[r0:r0 + 37800] = torch.randn(37800, C, device="cuda", generator=g) * 2 + 0.3
+    shift = torch.randn(C, device="cuda", generator=g) * 0.3
+    scale = torch.randn(C, device="cuda", generator=g) * 0.3
+    out = torch.empty(M, C, device="cuda", dtype=BF16)
+    H.layernorm_modulate(x, out, 1e-6, shift=shift, scale=scale)
+    rows = sample_rows(120, M, 9, EDGES_M)
+    ref = O.layer_norm(x[rows].cpu(), 1e-6) * (1 + scale.cpu()) + shift.cpu()
+    close(out[rows], ref, ulps=1.01, atol=1e-3, flip_frac=2e-3, flip_atol=4e-2)
+    # residual update + LayerNorm in one pass: x += res * gate, then the same norm
+    res = gpu_randn((M, C), 62)
+    gate = torch.randn(C, device="cuda", generator=g)
+    xr = x[rows].cpu() + res[rows].float().cpu() * gate.cpu()
+    H.resid_layernorm_modulate(x, res, out, 1e-6, res_gate=gate, shift=shift, scale=scale)
+    torch.testing.assert_close(x[rows].cpu(), xr, rtol=1e-6, atol=1e-6)
+    ref = O.layer_norm(xr, 1e-6) * (1 + scale.cpu()) + shift.cpu()
+    close(out[rows], ref, ulps=1.01, atol=1e-3, flip_frac=2e-3, flip_atol=4e-2)
+    del x, res, out
+    # RMSNorm + RoPE in place on the q columns of the fused projection buffer (row stride 3C)
+    qkv = torch.empty(M, 3 * C, device="cuda", dtype=BF16)
+    for r0 in range(0, M, 37800):
+        qkv[r0:r0 + 37800] = torch.randn(37800, 3 * C, device="cuda", generator=g).to(BF16)
+    before = qkv[rows].clone()
+    w = (gpu_randn((C,), 63, 0.2).float() + 1.0).to(BF16)
+    tab = build_rope_table(D, max(GRID), "cuda")
+    qv = qkv[:, C:2 * C]
+    H.rmsnorm_rope(qv, w, qv, D, 1e-6, rope=tab, rows_per_sample=L, n_rope=L, grid=GRID)
+    ang = O.rope_angles(D, GRID)
+    after = qkv[rows]
+    assert torch.equal(after[:, :C], before[:, :C]) and torch.equal(after[:, 2 * C:], before[:, 2 * C:])
+    for i, r in enumerate(rows[:40].tolist()):
+        tok = r % L
+        ref = O.rms_norm(before[i:i + 1, C:2 * C].float().cpu(), w.float().cpu(), 1e-6, "bf16")
+        ref = O.rope_rotate(ref.view(1, N, D), ang[tok:tok + 1])
+        close(after[i, C:2 * C].view(N, D), ref[0].to(BF16).float(), ulps=2.01, atol=2e-3, flip_frac=5e-3, flip_atol=6e-2)
+
+
+def test_one_a14b_block_full_grid_vs_oracle_rows():
+    """A 1-layer DiT of the A14B width (C = 5120, 40 heads, FFN 13 824) on the full 75 600-token grid,
+    both guidance branches, against the oracle (bf16 flow) at 40 sampled tokens: the oracle computes
+    K and V for the whole sequence and everything else for the sampled rows only
+    (oracle.dit.wan_forward_rows); a whole CPU forward at this size would take minutes."""
+    from omnivideo.modules.engine import DiTEngine
+    from omnivideo.modules.unified_model import UnifiedWanWithMixedConditionModel
+    cfg = syn.dit_config("A14B", num_layers=1, text_len=512)
+    sd = syn.make_unified_state_dict(cfg, 0)
+    m = UnifiedWanWithMixedConditionModel(wan_config=dict(cfg), vlm_in_dim=cfg["vlm_in_dim"],
+                                          use_visual_context_adapter=True,
+                                          visual_context_adapter_patch_size=cfg["visual_patch_size"],
+                                          max_context_len=cfg["text_len"], eps=cfg["eps"], skip_init=True)
+    m.load_state_dict(sd, strict=True)
+    wm = m.to(BF16).cuda().eval().wan_model
+    lat = syn.randn("a14b.lat", (16, 21, 90, 160), 1).to(BF16)
+    ctxs = [syn.randn("a14b.text", (20, cfg["text_dim"]), 1).to(BF16),
+            syn.randn("a14b.null", (126, cfg["text_dim"]), 1).to(BF16)]
+    eng = DiTEngine(wm)
+    eng.plan(GRID, L, 2)
+    cache = eng.encode_context([c.cuda() for c in ctxs], wm.text_len)
+    out = torch.empty(2, 16, 21, 90, 160, device="cuda")
+    eng.forward(lat.cuda(), torch.tensor([640.0], dtype=torch.float64, device="cuda"), cache, out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    rows = sample_rows(36, L, 12, (0, 79, 3600, L - 1)).tolist()
+    sdb = {k: v for k, v in O.round_weights_bf16(sd).items() if k.startswith("wan_model.")}
+    for b in (0, 1):
+        ref = O.wan_forward_rows(lat.float(), 640, ctxs[b].float(), L, sdb, cfg, rows, "bf16")
+        got = O.gather_token_patches(out[b].cpu(), rows, GRID, cfg["patch_size"])
+        rel = float((got - ref).norm() / ref.norm())
+        check_rel(f"A14B block, full grid, branch {b}, vs bf16 oracle rows", rel, 2e-4)   # observed 4.7e-5 / 6.3e-5

@@ -12,6 +12,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import check_rel
+
 from omnivideo.utils import synthetic as syn
 from oracle import dit as O
 
@@ -70,14 +72,14 @@ def test_self_and_cross_attention_modules(W, G):
     y = blk.self_attn(x.cuda().to(BF16), torch.tensor([72]), grid, None)
     ref = O.self_attention(O.rb(x[0], "bf16"), sdb, "wan_model.blocks.1.self_attn", 2, cfg["eps"],
                            O.rope_angles(128, (3, 4, 6)), 72, "bf16")
-    assert rel_l2(y[0], ref) < 1.5e-2
-    assert rel_l2(y[0], G["self_attn"]) < 3e-2
+    check_rel("self_attn vs bf16 oracle", rel_l2(y[0], ref), 9e-3)               # observed 2.9e-3
+    check_rel("self_attn vs reference fp32 golden", rel_l2(y[0], G["self_attn"]), 2e-2)   # observed 6.1e-3 (bf16 vs fp32 flow)
     c = syn.randn("probe.ctx", (1, 48, 256), 3)
     y = blk.cross_attn(x.cuda().to(BF16), c.cuda().to(BF16), None)
     kv = O.cross_kv(O.rb(c[0], "bf16"), sdb, "wan_model.blocks.1.cross_attn", cfg["eps"], "bf16")
     ref = O.cross_attention(O.rb(x[0], "bf16"), kv, sdb, "wan_model.blocks.1.cross_attn", 2, cfg["eps"], "bf16")
-    assert rel_l2(y[0], ref) < 1.5e-2
-    assert rel_l2(y[0], G["cross_attn"]) < 3e-2
+    check_rel("cross_attn vs bf16 oracle", rel_l2(y[0], ref), 9e-3)              # observed 2.9e-3
+    check_rel("cross_attn vs reference fp32 golden", rel_l2(y[0], G["cross_attn"]), 1.8e-2)   # observed 5.6e-3
 
 
 def test_attention_block_module(W, G):
@@ -91,8 +93,8 @@ def test_attention_block_module(W, G):
     ref = O.block_forward(x[0], e0[0, 0], kv, sdb, "wan_model.blocks.1", cfg, O.rope_angles(128, (3, 4, 6)), 72,
                           "bf16")
     assert y.dtype == F32
-    assert rel_l2(y[0], ref) < 1e-2
-    assert rel_l2(y[0], G["block"]) < 2e-2
+    check_rel("block vs bf16 oracle", rel_l2(y[0], ref), 1.2e-3)                 # observed 3.6e-4
+    check_rel("block vs reference fp32 golden", rel_l2(y[0], G["block"]), 2e-3)   # observed 6.1e-4
 
 
 def test_condition_pieces(W, G):
@@ -101,11 +103,11 @@ def test_condition_pieces(W, G):
     inp = inputs(cfg)
     v = m.visual_context_adapter(inp["visual"].cuda())
     assert v.dtype == F32 and tuple(v.shape) == (1, 18, cfg["text_dim"])
-    assert rel_l2(v[0], O.visual_adapter(inp["visual"][0], sdb, cfg, "bf16")) < 1e-2
-    assert rel_l2(v[0], G["visual_adapter"]) < 2e-2
+    check_rel("visual_adapter vs bf16 oracle", rel_l2(v[0], O.visual_adapter(inp["visual"][0], sdb, cfg, "bf16")), 1e-6)   # observed 6e-8
+    check_rel("visual_adapter vs reference fp32 golden", rel_l2(v[0], G["visual_adapter"]), 1.2e-2)   # observed 3.9e-3
     p = m._project_vlm(inp["ar"][0].cuda())
-    assert rel_l2(p, O.vlm_project(inp["ar"][0], sdb, cfg, "bf16")) < 1e-2
-    assert rel_l2(p, G["vlm_proj"]) < 2e-2
+    check_rel("vlm_proj vs bf16 oracle", rel_l2(p, O.vlm_project(inp["ar"][0], sdb, cfg, "bf16")), 1e-6)   # observed 0 (bit-exact)
+    check_rel("vlm_proj vs reference fp32 golden", rel_l2(p, G["vlm_proj"]), 1.3e-2)   # observed 4.1e-3
 
 
 CASES = {
@@ -140,8 +142,8 @@ def test_unified_forward(W, G, name):
     ref = O.unified_forward(lat.float(), case["t"], sdb, cfg_o, case["seq_len"], "bf16", text=inp[case["text"]],
                             ar_vision=ar, visual=inp["visual"] if case.get("visual") else None,
                             special=sp if case.get("special") else None)
-    assert rel_l2(out, ref) < 1.5e-2, rel_l2(out, ref)
-    assert rel_l2(out, G[name]) < 3e-2, rel_l2(out, G[name])
+    check_rel(f"unified forward {name} vs bf16 oracle", rel_l2(out, ref), 9e-4)                 # observed 2.3e-4 .. 2.8e-4
+    check_rel(f"unified forward {name} vs reference fp32 golden", rel_l2(out, G[name]), 1e-2)   # observed 3.1e-3: the bf16-vs-fp32 distance
     # second call hits the context cache and must reproduce the result exactly
     out2 = m([lat.cuda()], t=torch.tensor([case["t"]]), **kw)[0]
     assert torch.equal(out, out2)
@@ -170,3 +172,43 @@ def test_engine_cfg_batch_matches_single_branch(W):
     eng.forward(lat, t.to("cuda", torch.float64), eng.encode_context([c1, c3], m.text_len), out)
     assert torch.equal(out[0], a)
     assert rel_l2(out[1], c) < 2e-3, rel_l2(out[1], c)
+
+
+def test_head_forward_and_unpatchify_surface(W, G):
+    """`Head.forward` (reference model.py:278-290) and `WanModel.unpatchify` (:526-549) as callable
+    members of the module surface (the pipeline's forward fuses both into one kernel)."""
+    cfg, sd, sdb, _ = W
+    wm = build_unified(cfg, sd).wan_model
+    C = cfg["dim"]
+    x = syn.randn("probe.x", (1, 80, C), 3)
+    e = syn.randn("probe.e", (1, 1, C), 3, 0.3)
+    y = wm.head(x.cuda(), e.expand(1, 80, C).cuda())
+    assert y.dtype == F32 and tuple(y.shape) == (1, 80, 64)
+    m = sdb["wan_model.head.modulation"].reshape(2, -1) + e[0]
+    ref = torch.nn.functional.linear(O.layer_norm(x[0], cfg["eps"]) * (1 + m[1]) + m[0],
+                                     sdb["wan_model.head.head.weight"], sdb["wan_model.head.head.bias"])
+    check_rel("Head.forward vs oracle (bf16 weights, fp32 math)", rel_l2(y[0], ref), 1e-6)      # observed 3.1e-7
+    check_rel("Head.forward vs reference fp32 golden", rel_l2(y[0], G["head"]), 5e-3)           # observed 1.5e-3 (bf16-rounded weights)
+    assert torch.equal(wm.head(x.cuda(), e.cuda()), y)                    # [B, 1, C] broadcast form
+    with pytest.raises(NotImplementedError):
+        wm.head(x.cuda(), syn.randn("probe.e80", (1, 80, C), 3).cuda())
+    # unpatchify: a layout change; against the oracle's scatter
+    grid = (3, 4, 6)
+    vid = wm.unpatchify([y[0]], torch.tensor([grid]))[0]
+    assert tuple(vid.shape) == (16, 3, 8, 12)
+    assert torch.equal(O.gather_token_patches(vid.cpu(), list(range(72)), grid, cfg["patch_size"]), y[0, :72].cpu())
+
+
+def test_per_token_timestep_argument(W):
+    """t of shape [B, L] (reference model.py:467-476 expands one timestep per sample to every token)."""
+    cfg, sd, _, _ = W
+    wm = build_unified(cfg, sd).wan_model
+    inp = inputs(cfg)
+    lat, ctx = inp["lat"].cuda().to(BF16), inp["text"].cuda().to(BF16)
+    a = wm([lat], torch.tensor([650]), [ctx], 80)[0].clone()
+    b = wm([lat], torch.full((1, 80), 650), [ctx], 80)[0]
+    assert torch.equal(a, b)
+    t = torch.full((1, 80), 650)
+    t[0, 5] = 651
+    with pytest.raises(NotImplementedError):
+        wm([lat], t, [ctx], 80)

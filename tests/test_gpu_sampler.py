@@ -3,6 +3,8 @@ against the oracle sampler driving the oracle DiT."""
 import pytest
 import torch
 
+from conftest import check_rel
+
 from omnivideo.utils import synthetic as syn
 from oracle import dit as O
 from oracle import dpm as D
@@ -130,7 +132,7 @@ def test_generate_loop_matches_oracle(use_graph):
                                         ar_vision=rbw(ar_null), visual=visual, special=sp)
     ref = U.sample_loop(fc, fu, noise.clone(), steps, shift, guide)
     rel = float((lat.float().cpu() - ref.float()).norm() / ref.float().norm())
-    assert rel < 2e-2, rel
+    check_rel("test_generate_loop_matches_oracle", rel, 6e-3)      # observed 1.9e-3
 
 
 def test_generate_loop_dpmpp_matches_oracle():
@@ -153,7 +155,7 @@ def test_generate_loop_dpmpp_matches_oracle():
     fu = lambda l, t: O.unified_forward(l.float(), t, sdb, cfg, 72, "bf16", text=rbw(text_null), special=sp)
     ref = D.sample_loop(fc, fu, noise.clone(), steps, shift, guide)
     rel = float((lat.cpu() - ref).norm() / ref.norm())
-    assert rel < 2e-2, rel
+    check_rel("test_generate_loop_dpmpp_matches_oracle", rel, 2e-3)      # observed 6.7e-4
     with pytest.raises(NotImplementedError):
         pipe.generate("", precomputed_context=text.to(BF16), precomputed_context_null=text_null.to(BF16),
                       size=(96, 64), frame_num=9, sample_solver="euler", noise=noise, return_latents=True)
@@ -193,7 +195,7 @@ def test_two_expert_switch_at_noise_boundary():
     fu = lambda l, t: O.unified_forward(l.float(), t, pick(t), cfg, 72, "bf16", text=rbw(text_null), special=sp)
     ref = U.sample_loop(fc, fu, noise.clone(), steps, shift, guide)
     rel = float((lat.float().cpu() - ref.float()).norm() / ref.float().norm())
-    assert rel < 2e-2, rel
+    check_rel("test_two_expert_switch_at_noise_boundary", rel, 7e-3)      # observed 2.2e-3
     # one expert for every step gives a different answer: the switch is observable
     one = U.sample_loop(lambda l, t: O.unified_forward(l.float(), t, sdb[1], cfg, 72, "bf16", text=rbw(text), special=sp),
                         lambda l, t: O.unified_forward(l.float(), t, sdb[1], cfg, 72, "bf16", text=rbw(text_null),
@@ -248,7 +250,7 @@ def test_generate_returns_decoded_video_end_to_end():
     with torch.no_grad():
         ref_video = V.decode(ref_lat.float(), vsd, lay).clamp(-1, 1)
     rel = float((video.cpu() - ref_video).norm() / ref_video.norm())
-    assert rel < 3e-2, rel
+    check_rel("test_generate_returns_decoded_video_end_to_end", rel, 3e-2)      # observed 1.04e-2
 
 
 def test_v2v_input_path_frames_to_latents_to_generate():
@@ -287,4 +289,4 @@ def test_v2v_input_path_frames_to_latents_to_generate():
     fu = lambda l, t: O.unified_forward(l.float(), t, sdb, cfg, 72, "bf16", text=rbw(text_null), visual=vis, special=sp)
     ref = U.sample_loop(fc, fu, noise.clone(), 3, 5.0, 3.0)
     rel = float((lat.float().cpu() - ref.float()).norm() / ref.float().norm())
-    assert rel < 2e-2, rel
+    check_rel("test_v2v_input_path_frames_to_latents_to_generate", rel, 6e-3)      # observed 1.8e-3

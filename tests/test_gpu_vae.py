@@ -1,8 +1,14 @@
 """VAE parity on the GPU: the fused channels-last conv kernel against torch's fp32 conv on
 the CPU for every mode the VAE uses, then whole encode / decode of the reduced-width VAE
 through the reference-named `Wan2_1_VAE` surface against the oracle and against the
-goldens made by the reference's own WanVAE_.  Tolerance: fp32 round-off (the kernels are
-exact-fp32 MFMA; only the summation order differs)."""
+goldens made by the reference's own WanVAE_.
+
+Two arithmetic paths, both run here: the default computes every fp32 product as three bf16 MFMA
+products of the operands' hi / lo halves (relative error ~2^-16 per product, finer than the TF32
+that cuDNN convolutions default to, coarser than exact fp32) and is held to rtol 2e-4 per layer and
+1e-3 per whole encode / decode; OVD_VAE_EXACT_FP32=1 selects exact-fp32 MFMA (only the summation order
+differs from the reference) and is held to rtol 2e-5 / 1e-4.  The switch is read once per process, so
+the exact path runs in a fresh child process (test_exact_fp32_path_in_fresh_process)."""
 import os
 
 import numpy as np
@@ -14,7 +20,9 @@ from omnivideo.utils import synthetic as syn
 from oracle import vae as V
 
 pytestmark = pytest.mark.gpu
-RTOL, ATOL = 2e-4, 2e-5
+EXACT = os.environ.get("OVD_VAE_EXACT_FP32", "0") not in ("", "0")
+RTOL, ATOL = (2e-5, 2e-6) if EXACT else (2e-4, 2e-5)          # one layer
+RTOL_NET, ATOL_NET = (1e-4, 1e-5) if EXACT else (1e-3, 1e-4)    # whole encoder / decoder
 
 
 @pytest.fixture(scope="module")
@@ -165,9 +173,9 @@ def test_encode(vae, G, frames, hw):
     v, sd, lay = vae
     vid = syn.randn(f"vae.video{frames}", (3, frames, *hw), 5).clamp(-1, 1)
     z = v.encode([vid.cuda()])[0]
-    torch.testing.assert_close(z.cpu(), G[f"encode_{frames}"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(z.cpu(), G[f"encode_{frames}"], rtol=RTOL_NET, atol=ATOL_NET)
     with torch.no_grad():
-        torch.testing.assert_close(z.cpu(), V.encode(vid, sd, lay), rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(z.cpu(), V.encode(vid, sd, lay), rtol=RTOL_NET, atol=ATOL_NET)
 
 
 @pytest.mark.parametrize("tl,hw", [(2, (4, 6)), (3, (4, 4)), (1, (2, 2))])
@@ -176,7 +184,7 @@ def test_decode(vae, G, tl, hw):
     z = syn.randn(f"vae.z{tl}", (16, tl, *hw), 5)
     x = v.decode([z.cuda()])[0]
     assert tuple(x.shape) == (3, 4 * tl - 3, 8 * hw[0], 8 * hw[1])
-    torch.testing.assert_close(x.cpu(), G[f"decode_{tl}"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(x.cpu(), G[f"decode_{tl}"], rtol=RTOL_NET, atol=ATOL_NET)
 
 
 def test_decode_encode_round_trip_shapes(vae):
@@ -260,3 +268,16 @@ def test_frames_resize_rejects_bad_input():
         H.frames_resize_normalize(torch.zeros(1, 8, 8, 3, device="cuda"), (0, 0, 8, 8), (4, 4), lut)
     with pytest.raises(RuntimeError, match="crop window"):
         H.frames_resize_normalize(torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device="cuda"), (2, 0, 8, 8), (4, 4), lut)
+
+
+@pytest.mark.skipif(EXACT, reason="this is the child process")
+def test_exact_fp32_path_in_fresh_process():
+    """The same layer / encode / decode tests on the exact-fp32 matrix path at its tighter tolerance."""
+    import subprocess
+    import sys
+    env = dict(os.environ, OVD_VAE_EXACT_FP32="1")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                          "conv or encode or decode", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-2000:]
+    assert " passed" in res.stdout and "failed" not in res.stdout, res.stdout[-1000:]

@@ -137,3 +137,25 @@ def test_bf16_flow_stays_near_fp32(G, W):
                           ar_vision=inp["ar"], visual=inp["visual"], special=sp)
     rel = (y - G["full_special_pad"]).norm() / G["full_special_pad"].norm()
     assert rel < 3e-2, rel
+
+
+@pytest.mark.parametrize("flow", ["fp32", "bf16"])
+def test_sampled_row_forward_equals_whole_forward(flow):
+    """wan_forward_rows (one layer, sampled token rows; what the A14B-geometry GPU test compares
+    against) reproduces the same rows of wan_forward exactly, padded sequence tail included."""
+    import torch
+    from omnivideo.utils import synthetic as syn
+    from oracle import dit as O
+    cfg = syn.dit_config("tiny", num_layers=1)
+    sd = syn.make_unified_state_dict(cfg, 0)
+    if flow == "bf16":
+        sd = O.round_weights_bf16(sd)
+    lat = syn.randn("rows.lat", (16, 3, 8, 12), 1)
+    ctx = syn.randn("rows.text", (10, cfg["text_dim"]), 1)
+    full = O.wan_forward(lat, 640, ctx, 80, sd, cfg, flow)
+    rows = [0, 1, 17, 40, 70, 71]
+    got = O.wan_forward_rows(lat, 640, ctx, 80, sd, cfg, rows, flow)
+    want = O.gather_token_patches(full, rows, (3, 4, 6), cfg["patch_size"])
+    # fp32: summation order of the row-subset matmuls only; bf16 flow: that order can flip a rounding
+    tol = dict(rtol=1e-5, atol=1e-6) if flow == "fp32" else dict(rtol=2e-3, atol=5e-5)
+    torch.testing.assert_close(got, want, **tol)
