@@ -208,7 +208,7 @@ def main():
         n_high = sum(1 for m in by_step if m is experts[0]) if len(experts) == 2 else None
         lat = noise.clone()
         seq_len = wl["latent"][1] * (wl["latent"][2] // 2) * (wl["latent"][3] // 2)
-        use_graph = not args.no_graph and (not sp or getattr(comm, "capturable", False))
+        use_graph = not args.no_graph      # under sequence parallelism: graphs between eager collectives
         loop = DenoiseLoop(by_step, lat, pairs, seq_len, sched, 3.0, use_graph=use_graph, comm=comm)
         run = loop.run
 

@@ -70,6 +70,30 @@ int ovd_rmsnorm_rope_bf16(const uint16_t* in, int64_t ldi, const uint16_t* weigh
                           int rows_per_sample, int tok_offset, int n_rope, int gf, int gh, int gw,
                           void* stream);
 
+/* ovd_rmsnorm_rope_bf16 for the q and k thirds of fused projection rows qkv [M, 3C] (q | k | v, row stride
+ * ld) in ONE launch, each third with its own RMSNorm weight, both rotated; with copy_v the v third is
+ * copied along unchanged.  The result of third p goes to out + p * out_part_stride, its C columns split
+ * into blocks of col_block columns that sit out_block_stride elements apart; row m of a block starts at
+ * (m / rows_per_sample) * out_sample_stride + (m % rows_per_sample) * ldo.
+ *   in place:  out = qkv, ldo = ld, out_part_stride = C, col_block = C, out_sample_stride =
+ *              rows_per_sample * ld, copy_v = 0  (what WanSelfAttention.forward does at model.py:137-149);
+ *   sequence parallelism: out = the all-to-all send image [3][samples][p ranks][rows][C/p] (col_block =
+ *              ldo = C/p, out_block_stride = rows * C/p, out_sample_stride = p * rows * C/p, out_part_stride
+ *              = samples * p * rows * C/p, copy_v = 1): the head-scatter of Ulysses attention
+ *              (omnivideo/distributed/ulysses.py:41-43, util.py:106-109 chunk + contiguous copies) written by
+ *              the kernel that produces q and k, so no separate packing pass exists. */
+int ovd_qkv_norm_rope_bf16(const uint16_t* qkv, int64_t ld, const uint16_t* weight_q, const uint16_t* weight_k,
+                           const float* rope, int rope_rows, uint16_t* out, int64_t ldo, int64_t out_part_stride,
+                           int col_block, int64_t out_block_stride, int64_t out_sample_stride, int copy_v, int M,
+                           int C, int head_dim, float eps, int rows_per_sample, int tok_offset, int n_rope, int gf,
+                           int gh, int gw, void* stream);
+
+/* dst[m][b * col_block + c] = src[b][m][c], b < nblk, m < M (dst row stride ldd): the head-gather after
+ * the second all-to-all of Ulysses attention (ulysses.py:55; util.py:106-109 cat along the head dim) -
+ * the attention output of every head group, received one group after another, back into token rows. */
+int ovd_gather_col_blocks_bf16(const uint16_t* src, uint16_t* dst, int64_t ldd, int64_t M, int nblk, int col_block,
+                               void* stream);
+
 /* out = epilogue(A[M,K] * W[N,K]^T + bias[N]), bf16 operands, fp32 accumulation.
  * epilogue 0: bf16 out; 1: bf16 out of tanh-GELU(bf16-rounded pre-activation);
  * 2: fp32 out holding the bf16-rounded value; 3: fp32 in-place residual

@@ -110,9 +110,20 @@ int ovd_impl_ln_f32(float* x, long ldx, const bf16_t* res, long ldr, const float
 // rotated load from clamped addresses and discard the value, so the kernel has no branch between
 // its loads and every load is in flight before the first use.
 // WPR waves share one row, as in ln_row.h: chunk i of a lane is 16-byte chunk (i * WPR + wave) * 64 + lane.
+// Several row-parts in one launch (blockIdx.y = part): the q | k | v thirds of a fused projection row.
+// Part p reads columns [p * in_part_stride, + C) of the input row and uses weight[p]; part 2 (v) is copied
+// unchanged.  The output row of part p goes to out + p * out_part_stride, split into column blocks of
+// cb8 16-byte chunks that sit out_block_stride elements apart, at row offset
+// (row / rows_per_sample) * out_sample_stride + (row % rows_per_sample) * ldo: in place this is the input
+// layout itself; for sequence parallelism it is the all-to-all send image [part][sample][dest rank][row][C/p].
+struct RnParts {
+    const bf16_t* weight[2];
+    long in_part_stride, out_part_stride, out_block_stride, out_sample_stride;
+    int cb8;
+};
+
 template <int NCH, int WPR, bool WEIGHT, bool ROPE>
-__global__ void __launch_bounds__(256) rmsnorm_rope_kernel(const bf16_t* __restrict__ in, long ldi,
-                                                           const bf16_t* __restrict__ weight,
+__global__ void __launch_bounds__(256) rmsnorm_rope_kernel(const bf16_t* __restrict__ in, long ldi, RnParts pp,
                                                            const float2* __restrict__ rope, int rope_rows,
                                                            bf16_t* __restrict__ out, long ldo, int M, int C,
                                                            int D, float eps, int rows_per_sample,
@@ -125,17 +136,33 @@ __global__ void __launch_bounds__(256) rmsnorm_rope_kernel(const bf16_t* __restr
     } else {
         row = live ? row : M - 1;     // keeps the block's barrier matched; stores nothing
     }
+    const int part = blockIdx.y;
     const int nchunk = C >> 3;
     auto chunk = [&](int i) -> int { return (i * WPR + (int)((threadIdx.x >> 6) & (WPR - 1))) * 64 + (int)(threadIdx.x & 63); };
-    const uint4* src = reinterpret_cast<const uint4*>(in + (long)row * ldi);
+    const uint4* src = reinterpret_cast<const uint4*>(in + (long)row * ldi + part * pp.in_part_stride);
+    const int srow = row % rows_per_sample;
+    bf16_t* orow = out + part * pp.out_part_stride + (long)(row / rows_per_sample) * pp.out_sample_stride + (long)srow * ldo;
+    auto ochunk = [&](int c) -> uint4* {      // where 16-byte chunk c of this row goes
+        const int blk = pp.cb8 == nchunk ? 0 : c / pp.cb8;
+        return reinterpret_cast<uint4*>(orow + (long)blk * pp.out_block_stride + (long)(c - blk * pp.cb8) * 8);
+    };
     uint4 raw[NCH], wq[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) raw[i] = src[min(chunk(i), nchunk - 1)];
-    if constexpr (WEIGHT) {
+    if (part == 2) {                  // v: no normalisation, no rotation
+        if (live) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) wq[i] = reinterpret_cast<const uint4*>(weight)[min(chunk(i), nchunk - 1)];
+            for (int i = 0; i < NCH; ++i)
+                if (chunk(i) < nchunk) *ochunk(chunk(i)) = raw[i];
+        }
+        return;                       // (block-uniform: every wave of the block has the same part)
     }
-    const int tok = (row % rows_per_sample) + tok_offset;
+    if constexpr (WEIGHT) {
+        const uint4* wsrc = reinterpret_cast<const uint4*>(pp.weight[part]);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) wq[i] = wsrc[min(chunk(i), nchunk - 1)];
+    }
+    const int tok = srow + tok_offset;
     const bool rotate = ROPE && tok < n_rope;
     float2 cs[NCH][4];
     if constexpr (ROPE) {
@@ -189,16 +216,17 @@ __global__ void __launch_bounds__(256) rmsnorm_rope_kernel(const bf16_t* __restr
             }
             o[j] = pack_bf2(a, b);
         }
-        if (c < nchunk) *reinterpret_cast<uint4*>(out + (long)row * ldo + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (c < nchunk) *ochunk(c) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
-int ovd_impl_rmsnorm_rope(const bf16_t* in, long ldi, const bf16_t* weight, const float* rope, int rope_rows,
-                          bf16_t* out, long ldo, int M, int C, int D, float eps, int rows_per_sample,
-                          int tok_offset, int n_rope, int gf, int gh, int gw, hipStream_t st) {
+static int launch_rmsnorm_rope(const bf16_t* in, long ldi, const RnParts& pp, int parts, bool has_weight,
+                               const float* rope, int rope_rows, bf16_t* out, long ldo, int M, int C, int D, float eps,
+                               int rows_per_sample, int tok_offset, int n_rope, int gf, int gh, int gw,
+                               hipStream_t st) {
     OVD_REQUIRE(C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0, "rmsnorm: C and row strides must be multiples of 8");
     OVD_REQUIRE(rows_per_sample > 0, "rmsnorm: rows_per_sample must be positive");
-    OVD_REQUIRE(weight != nullptr || rope != nullptr, "rmsnorm: neither weight nor rope given");
+    OVD_REQUIRE(has_weight || rope != nullptr, "rmsnorm: neither weight nor rope given");
     if (rope) {
         OVD_REQUIRE(D > 0 && (D & (D - 1)) == 0 && C % D == 0, "rmsnorm: head_dim must be a power of two dividing C");
         OVD_REQUIRE(gf > 0 && gh > 0 && gw > 0 && n_rope <= (long)gf * gh * gw,
@@ -210,15 +238,15 @@ int ovd_impl_rmsnorm_rope(const bf16_t* in, long ldi, const bf16_t* weight, cons
     const int nch = ceil_div(C / 8, 64);
     OVD_REQUIRE(nch <= 12, "rmsnorm: unsupported width C=%d (at most 6144)", C);
     const int wpr = nch <= 4 ? 1 : (nch <= 8 ? 2 : 4);
-    dim3 grid(ceil_div(M, 4 / wpr)), blk(256);
+    dim3 grid(ceil_div(M, 4 / wpr), parts), blk(256);
 #define RN_LAUNCH(V, P, W, R)                                                                           \
-    hipLaunchKernelGGL((rmsnorm_rope_kernel<V, P, W, R>), grid, blk, 0, st, in, ldi, weight,            \
+    hipLaunchKernelGGL((rmsnorm_rope_kernel<V, P, W, R>), grid, blk, 0, st, in, ldi, pp,                \
                        reinterpret_cast<const float2*>(rope), rope_rows, out, ldo, M, C, D, eps,        \
                        rows_per_sample, tok_offset, n_rope, gh, gw)
 #define RN_CASE(V, P)                                                                                   \
     case V * 8 + P:                                                                                     \
-        if (weight && rope) RN_LAUNCH(V, P, true, true);                                                \
-        else if (weight) RN_LAUNCH(V, P, true, false);                                                  \
+        if (has_weight && rope) RN_LAUNCH(V, P, true, true);                                            \
+        else if (has_weight) RN_LAUNCH(V, P, true, false);                                              \
         else RN_LAUNCH(V, P, false, true);                                                              \
         break;
     switch (ceil_div(nch, wpr) * 8 + wpr) {
@@ -229,5 +257,68 @@ int ovd_impl_rmsnorm_rope(const bf16_t* in, long ldi, const bf16_t* weight, cons
 #undef RN_LAUNCH
 #undef RN_CASE
     OVD_CHECK_LAUNCH("rmsnorm_rope");
+    return 0;
+}
+
+int ovd_impl_rmsnorm_rope(const bf16_t* in, long ldi, const bf16_t* weight, const float* rope, int rope_rows,
+                          bf16_t* out, long ldo, int M, int C, int D, float eps, int rows_per_sample,
+                          int tok_offset, int n_rope, int gf, int gh, int gw, hipStream_t st) {
+    RnParts pp;
+    pp.weight[0] = pp.weight[1] = weight;
+    pp.in_part_stride = pp.out_part_stride = pp.out_block_stride = 0;
+    pp.out_sample_stride = (long)rows_per_sample * ldo;       // plain rows: row m at m * ldo
+    pp.cb8 = C / 8;
+    return launch_rmsnorm_rope(in, ldi, pp, 1, weight != nullptr, rope, rope_rows, out, ldo, M, C, D, eps,
+                               rows_per_sample, tok_offset, n_rope, gf, gh, gw, st);
+}
+
+// q | k | v thirds of fused projection rows [M, 3C] in one launch: RMSNorm (own weight each) + RoPE on q and k;
+// v is copied when copy_v (its destination differs from its source).  Output layout: struct RnParts.
+int ovd_impl_qkv_norm_rope(const bf16_t* qkv, long ld, const bf16_t* wq, const bf16_t* wk, const float* rope,
+                           int rope_rows, bf16_t* out, long ldo, long out_part_stride, int col_block,
+                           long out_block_stride, long out_sample_stride, int copy_v, int M, int C, int D, float eps,
+                           int rows_per_sample, int tok_offset, int n_rope, int gf, int gh, int gw, hipStream_t st) {
+    OVD_REQUIRE(col_block > 0 && col_block % 8 == 0 && C % col_block == 0,
+                "qkv_norm_rope: col_block=%d must be a multiple of 8 dividing C=%d", col_block, C);
+    OVD_REQUIRE(ld >= 3L * C, "qkv_norm_rope: input rows shorter than 3*C");
+    OVD_REQUIRE(out_part_stride % 8 == 0 && out_block_stride % 8 == 0 && out_sample_stride % 8 == 0,
+                "qkv_norm_rope: output strides must be multiples of 8 elements");
+    RnParts pp;
+    pp.weight[0] = wq;
+    pp.weight[1] = wk;
+    pp.in_part_stride = C;
+    pp.out_part_stride = out_part_stride;
+    pp.out_block_stride = out_block_stride;
+    pp.out_sample_stride = out_sample_stride;
+    pp.cb8 = col_block / 8;
+    return launch_rmsnorm_rope(qkv, ld, pp, copy_v ? 3 : 2, true, rope, rope_rows, out, ldo, M, C, D, eps,
+                               rows_per_sample, tok_offset, n_rope, gf, gh, gw, st);
+}
+
+// dst[m][b * cb + c] = src[b][m][c]: column blocks that arrive one after another (the attention output of
+// each head group after the sequence-parallel all-to-all) back into rows.  16 bytes per lane.
+__global__ void __launch_bounds__(256) gather_col_blocks_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                                long M, int nblk, int cb8, long ldd8) {
+    const long total = M * nblk * cb8;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cb8);
+        const long t = i / cb8;
+        const long m = t % M;
+        const int b = (int)(t / M);
+        dst[m * ldd8 + (long)b * cb8 + c] = src[i];
+    }
+}
+
+int ovd_impl_gather_col_blocks(const bf16_t* src, bf16_t* dst, long ldd, long M, int nblk, int col_block,
+                               hipStream_t st) {
+    OVD_REQUIRE(col_block > 0 && col_block % 8 == 0 && ldd % 8 == 0 && ldd >= (long)nblk * col_block,
+                "gather_col_blocks: col_block=%d and the destination stride must be multiples of 8", col_block);
+    OVD_REQUIRE(M >= 0 && nblk > 0, "gather_col_blocks: bad shape");
+    if (M == 0) return 0;
+    const long total = M * nblk * (col_block / 8);
+    const int blocks = (int)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
+    hipLaunchKernelGGL(gather_col_blocks_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<uint4*>(dst), M, nblk, col_block / 8, ldd / 8);
+    OVD_CHECK_LAUNCH("gather_col_blocks");
     return 0;
 }

@@ -9,7 +9,8 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libomnihip.so")
+# OVD_LIB_PATH: load another build of the library (kernel-variant timing; the default is the in-tree build)
+_LIB_PATH = os.environ.get("OVD_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libomnihip.so")
 _lib = None
 
 _i, _l, _f, _p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -18,6 +19,8 @@ SIGNATURES = {
     "ovd_layernorm_modulate_bf16": [_p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _f, _i, _p],
     "ovd_layernorm_modulate_f32": [_p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _f, _i, _p],
     "ovd_rmsnorm_rope_bf16": [_p, _l, _p, _p, _i, _p, _l, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p],
+    "ovd_qkv_norm_rope_bf16": [_p, _l, _p, _p, _p, _i, _p, _l, _l, _i, _l, _l, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p],
+    "ovd_gather_col_blocks_bf16": [_p, _p, _l, _l, _i, _i, _p],
     "ovd_gemm_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _p],
     "ovd_flash_attn_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p],
     "ovd_flash_attn_tail_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p],
@@ -78,8 +81,13 @@ def lib():
     return _lib
 
 
+CALLS = 0          # entry-point calls made by this process (segmented graph capture counts launches with it)
+
+
 def _call(name, *args):
+    global CALLS
     L = lib()
+    CALLS += 1
     rc = getattr(L, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name}: {L.ovd_last_error().decode()}")
@@ -177,6 +185,40 @@ def rmsnorm_rope(x, weight, out, head_dim, eps, rope=None, rows_per_sample=None,
           _ptr(out, BF16), ldo, M, C, head_dim, float(eps), rows_per_sample or max(M, 1), tok_offset, n_rope,
           grid[0], grid[1], grid[2], _stream())
     return out
+
+
+def qkv_norm_rope(qkv, wq, wk, head_dim, eps, rope, rows_per_sample, tok_offset, n_rope, grid, send=None):
+    """RMSNorm + RoPE of the q and k thirds of fused projection rows qkv [M, 3C] in one launch.
+    send = None: in place.  send = [3, samples, p, rows, C/p] (contiguous): q, k (normalised, rotated) and v
+    are written there split by destination rank - the send image of the sequence-parallel all-to-all."""
+    M, C3, ld = _rows(qkv)
+    C = C3 // 3
+    if wq.numel() != C or wk.numel() != C:
+        raise ValueError("qkv_norm_rope: weight length must be C")
+    if rope.dtype != F32 or rope.dim() != 4 or rope.shape[0] != 3 or rope.shape[2] != head_dim // 2 \
+            or rope.shape[3] != 2 or not rope.is_contiguous():
+        raise ValueError("qkv_norm_rope: rope table must be contiguous fp32 [3, rows, head_dim/2, 2]")
+    if send is None:
+        out, ldo, part, cb, blk, samp, copy_v = qkv, ld, C, C, 0, rows_per_sample * ld, 0
+    else:
+        if send.dim() != 5 or not send.is_contiguous() or send.shape[0] != 3 or send.shape[3] != rows_per_sample \
+                or send.shape[2] * send.shape[4] != C or send.shape[1] * rows_per_sample != M:
+            raise ValueError("qkv_norm_rope: send buffer must be contiguous [3, samples, p, rows_per_sample, C/p]")
+        _, ns, p, rows, cb = send.shape
+        out, ldo, part, blk, samp, copy_v = send, cb, ns * p * rows * cb, rows * cb, p * rows * cb, 1
+    _call("ovd_qkv_norm_rope_bf16", _ptr(qkv, BF16), ld, _ptr(wq, BF16), _ptr(wk, BF16), _ptr(rope, F32), rope.shape[1],
+          _ptr(out, BF16), ldo, part, cb, blk, samp, copy_v, M, C, head_dim, float(eps), rows_per_sample, tok_offset,
+          n_rope, grid[0], grid[1], grid[2], _stream())
+
+
+def gather_col_blocks(src, dst):
+    """src [nblk, M, cb] contiguous -> dst [M, nblk * cb] (row stride free): dst[m, b*cb + c] = src[b, m, c]."""
+    nblk, M, cb = src.shape
+    Md, Cd, ldd = _rows(dst)
+    if not src.is_contiguous() or Md != M or Cd != nblk * cb:
+        raise ValueError("gather_col_blocks: shape mismatch")
+    _call("ovd_gather_col_blocks_bf16", _ptr(src, BF16), _ptr(dst, BF16), ldd, M, nblk, cb, _stream())
+    return dst
 
 
 def gemm(a, w, out, bias=None, epilogue=EPI_BF16, gate=None):

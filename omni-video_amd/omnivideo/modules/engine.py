@@ -235,12 +235,10 @@ class DiTEngine:
         self.attn_ws = torch.empty(ws, dtype=torch.uint8, device=dev) if ws > 0 else None
         if sp > 1:
             Cs = C // sp
-            self.sp_send = e(sp, 3, nb, S, Cs)        # q|k|v of my rows, split by destination head group
-            self.sp_recv = e(sp, 3, nb, S, Cs)        # q|k|v of every rank's rows for my head group
-            self.sp_qkv = e(3, nb, seq_len, Cs)       # full sequence, my heads
-            self.sp_o = e(nb, seq_len, Cs)
-            self.sp_osend = e(sp, nb, S, Cs)
-            self.sp_orecv = e(sp, nb, S, Cs)
+            self.sp_send = e(3, nb, sp, S, Cs)        # q|k|v of my rows, split by destination head group
+            self.sp_qkv = e(3, nb, seq_len, Cs)       # the full sequence for my head group (received in place)
+            self.sp_o = e(nb, seq_len, Cs)            # attention output, full sequence, my head group
+            self.sp_orecv = e(nb, sp, S, Cs)          # every head group's output for my rows
         self.grid, self.seq_len, self.nb, self.n_tok = tuple(grid), seq_len, nb, n_tok
         self.comm, self.sp, self.S, self.row0 = comm, sp, S, rank * S
         self._shape = key
@@ -279,23 +277,25 @@ class DiTEngine:
             ev[1].record()
             self.timing.append(ev)
 
-    def _self_attention_sp(self):
-        """Ulysses exchange around the attention kernel (reference ulysses.py:41-55): the q, k
-        and v of this rank's rows go out split by head group in one all-to-all; attention runs
-        over the full sequence for this rank's heads; one all-to-all brings the output back."""
-        C, N, D, nb, S, sp = self.dim, self.num_heads, self.head_dim, self.nb, self.S, self.sp
-        Cs = C // sp
-        # pack: send[j, part, b, s, :] = qkv[b, s, part*C + j*Cs : part*C + (j+1)*Cs]
-        self.sp_send.copy_(self.qkv.view(nb, S, 3, sp, Cs).permute(3, 2, 0, 1, 4))
-        self.comm.all_to_all(self.sp_recv, self.sp_send)
-        # unpack: full[part, b, i*S + s, :] = recv[i, part, b, s, :]
-        self.sp_qkv.view(3, nb, sp, S, Cs).copy_(self.sp_recv.permute(1, 2, 0, 3, 4))
+    def _self_attention_sp(self, L):
+        """Ulysses exchange around the attention kernel (reference ulysses.py:41-55).  The kernel that
+        normalises and rotates q and k writes q, k and v straight into the all-to-all send image (split
+        by destination head group); each (tensor, guidance branch) slab is exchanged on its own so that
+        what arrives IS the full sequence for this rank's heads, which the attention kernel reads in
+        place; its output goes back the same way and one gather kernel restores token rows.  No packing
+        or unpacking copies (the reference chunks, copies and concatenates around each of its four
+        all-to-alls, util.py:106-109)."""
+        N, D, nb, S, sp = self.num_heads, self.head_dim, self.nb, self.S, self.sp
+        H.qkv_norm_rope(self.qkv.view(nb * S, -1), L["nq"], L["nk"], D, self.eps, self.rope, S, self.row0,
+                        self.n_tok, self.grid, send=self.sp_send)
+        for part in range(3):
+            for b in range(nb):
+                self.comm.all_to_all(self.sp_qkv[part, b].view(sp, S, -1), self.sp_send[part, b])
         q4, k4, v4 = (self.sp_qkv[i].unflatten(2, (N // sp, D)) for i in range(3))
         self._self_attention(q4, k4, v4, self.sp_o.unflatten(2, (N // sp, D)))
-        # back: osend[j, b, s, :] = o[b, j*S + s, :]  ->  att[b, s, i*Cs:(i+1)*Cs] = orecv[i, b, s, :]
-        self.sp_osend.copy_(self.sp_o.view(nb, sp, S, Cs).permute(1, 0, 2, 3))
-        self.comm.all_to_all(self.sp_orecv, self.sp_osend)
-        self.att.view(nb, S, sp, Cs).copy_(self.sp_orecv.permute(1, 2, 0, 3))
+        for b in range(nb):
+            self.comm.all_to_all(self.sp_orecv[b], self.sp_o[b].view(sp, S, -1))
+            H.gather_col_blocks(self.sp_orecv[b], self.att[b])
 
     # ------------------------------------------------------------------ sub-layer pieces
     def _norm(self, x2, pending, **kw):
@@ -363,13 +363,10 @@ class DiTEngine:
                 H.gemm_fp8(self.h8, L["w8_qkv"], L["s_qkv"], qkv2, L["b_qkv"], H.EPI_BF16, a_scale=self.h_scale)
             else:
                 H.gemm(self.h, L["w_qkv"], qkv2, L["b_qkv"], H.EPI_BF16)
-            for sl, nw in ((slice(0, C), L["nq"]), (slice(C, 2 * C), L["nk"])):
-                v_ = qkv2[:, sl]
-                H.rmsnorm_rope(v_, nw, v_, D, self.eps, rope=self.rope, rows_per_sample=S, tok_offset=row0,
-                               n_rope=n_tok, grid=self.grid)
             if self.sp > 1:
-                self._self_attention_sp()
+                self._self_attention_sp(L)
             else:
+                H.qkv_norm_rope(qkv2, L["nq"], L["nk"], D, self.eps, self.rope, S, row0, n_tok, self.grid)
                 self._self_attention(q4, k4, v4, att4)
             self._linear_from_attention(att2, L, "o")
             pending = (self.res, mod[2])

@@ -8,7 +8,8 @@ What changes underneath, with unchanged arithmetic per element:
   * guidance combine + UniPC update is one fused launch per step;
   * a whole step (2 forwards + update) is captured once per expert into a HIP graph and
     replayed; the step index lives on the device, so the loop has no host
-    synchronisation (the reference syncs on `t.item()` every step, :235);
+    synchronisation (the reference syncs on `t.item()` every step, :235); under sequence
+    parallelism the step is a chain of graphs with the collectives issued between them;
   * both experts stay resident in HBM (288 GB): no CPU offload round trips.
 Not provided: FSDP sharding.  The umT5 text encoder (modules/t5.py) is attached when
 `checkpoint_dir` holds its checkpoint and tokenizer files; otherwise text conditions come in as
@@ -31,6 +32,59 @@ from .utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigm
 from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 
 BF16, F32 = torch.bfloat16, torch.float32
+
+
+class _SegmentedGraph:
+    """One sampling step of a sequence-parallel rank as a chain of HIP graphs with the collectives
+    between them: the launches from one collective to the next are captured into a graph each, the
+    collectives themselves are recorded as calls and issued eagerly at replay, in the same order on
+    every rank.  (A graph cannot hold a collective that is staged through the host, and keeping RCCL
+    calls outside the graphs makes the replayed step independent of the communicator in use.)"""
+
+    class _Recorder:
+        def __init__(self, owner, comm):
+            self._o, self._c = owner, comm
+            self.size, self.rank = comm.size, comm.rank
+
+        def __getattr__(self, name):
+            fn = getattr(self._c, name)
+
+            def call(*args):
+                self._o._close()
+                self._o.items.append((fn, args))
+                self._o._open()
+            return call
+
+    def __init__(self, step_fn, engine):
+        self.items = []
+        self._ctx = self._g = None
+        comm = engine.comm
+        engine.comm = self._Recorder(self, comm)
+        try:
+            self._open()
+            step_fn()
+            self._close()
+        finally:
+            engine.comm = comm
+
+    def _open(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(self._g, capture_error_mode="thread_local")
+        self._n0 = H.CALLS
+        self._ctx.__enter__()
+
+    def _close(self):
+        self._ctx.__exit__(None, None, None)
+        if H.CALLS > self._n0:                  # segments without a launch (two collectives in a row) are dropped
+            self.items.append((self._g, None))
+        self._g = self._ctx = None
+
+    def replay(self):
+        for item, args in self.items:
+            if args is None:
+                item.replay()
+            else:
+                item(*args)
 
 
 class DenoiseLoop:
@@ -87,10 +141,14 @@ class DenoiseLoop:
             self._step(key)
             for b, c in saved:
                 b.copy_(c)
-            g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
-                self._step(key)
+            if self.engines[key].comm is not None:
+                # sequence parallel: graphs between the collectives, collectives eager
+                g = _SegmentedGraph(lambda: self._step(key), self.engines[key])
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step(key)
             self.graphs[key] = g
 
     def seek(self, i):
@@ -330,9 +388,9 @@ class OmniVideoX2XUnified:
                     c = m.build_mixed_context(1, context, ar_vision_input, visual_emb, self.special_tokens)[0]
                     u = m.build_mixed_context(1, context_null, ar_null, visual_emb, self.special_tokens)[0]
                     pairs[id(m)] = (c, u)
-            # collectives are not captured: with sequence parallelism the step runs eagerly
-            loop = DenoiseLoop(models, lat, pairs, seq_len, sched, guide_scale,
-                               use_graph=self.use_graph and self.sp_comm is None, comm=self.sp_comm)
+            # with sequence parallelism the step replays as graphs between eager collectives
+            loop = DenoiseLoop(models, lat, pairs, seq_len, sched, guide_scale, use_graph=self.use_graph,
+                               comm=self.sp_comm)
             lat = loop.run()
             if dist.is_initialized():
                 dist.barrier()

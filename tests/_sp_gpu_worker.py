@@ -23,7 +23,12 @@ def case_generate(outdir, rank, world):
     assert wm.forward.__func__.__name__ == "sp_dit_forward"
     assert wm.blocks[0].self_attn.forward.__func__.__name__ == "sp_attn_forward"
     assert wm.blocks[0].cross_attn.forward.__func__.__name__ == "sp_cross_attn_forward"
-    lat, video = case.run_generate(pipe, cfg)
+    lat, video = case.run_generate(pipe, cfg)                 # graphs between eager collectives
+    from omnivideo.x2x_gen_unified import _SegmentedGraph
+    pipe.use_graph = False
+    lat_eager, _ = case.run_generate(pipe, cfg)               # every launch eager
+    if lat is not None:
+        assert torch.equal(lat, lat_eager), "segmented graph replay differs from the eager step"
     # the model-level entry the pipeline binds (sp_dit_forward): every rank gets the full output
     kw = case.generate_inputs(cfg)
     t = torch.tensor([640.0], device="cuda")

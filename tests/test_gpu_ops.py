@@ -409,3 +409,37 @@ def test_reference_signature_flash_attention_lens_scale_dtype():
         flash_attention(dev(q), dev(k), dev(v), q_lens=torch.tensor([Lq, Lq - 1]))
     with pytest.raises(NotImplementedError):
         flash_attention(dev(q), dev(k), dev(v), causal=True)
+
+
+@pytest.mark.parametrize("C,heads,S,nb,p", [(256, 2, 40, 2, 2), (1536, 12, 52, 2, 4), (5120, 40, 19, 2, 8), (512, 4, 36, 1, 1)])
+def test_qkv_norm_rope_fused_launch_and_send_image(H, C, heads, S, nb, p):
+    """One launch for the q and k thirds (own weights, RoPE) equals the two single launches bit for bit;
+    with a send buffer it writes q, k, v split by destination rank - the all-to-all image that torch
+    chunk/stack copies would build; gather_col_blocks is the inverse regrouping of the way back."""
+    from omnivideo.modules.engine import build_rope_table
+    D, grid, tok0 = C // heads, (3, 4, 6), 30
+    n_tok = 72
+    g = torch.Generator(device="cuda").manual_seed(C + S)
+    qkv = torch.randn(nb * S, 3 * C, device="cuda", generator=g).to(BF16)
+    wq = (torch.randn(C, device="cuda", generator=g) * 0.2 + 1).to(BF16)
+    wk = (torch.randn(C, device="cuda", generator=g) * 0.2 + 1).to(BF16)
+    rope = build_rope_table(D, max(grid), "cuda")
+    ref = qkv.clone()
+    for i, w in ((0, wq), (1, wk)):
+        v_ = ref[:, i * C:(i + 1) * C]
+        H.rmsnorm_rope(v_, w, v_, D, 1e-6, rope=rope, rows_per_sample=S, tok_offset=tok0, n_rope=n_tok, grid=grid)
+    inplace = qkv.clone()
+    H.qkv_norm_rope(inplace, wq, wk, D, 1e-6, rope, S, tok0, n_tok, grid)
+    assert torch.equal(inplace, ref)
+    Cs = C // p
+    send = torch.full((3, nb, p, S, Cs), float("nan"), device="cuda", dtype=BF16)
+    src = qkv.clone()
+    H.qkv_norm_rope(src, wq, wk, D, 1e-6, rope, S, tok0, n_tok, grid, send=send)
+    assert torch.equal(src, qkv)                                   # the input is left alone
+    want = ref.view(nb, S, 3, p, Cs).permute(2, 0, 3, 1, 4)        # [part, sample, dest, row, C/p]
+    assert torch.equal(send, want)
+    # the way back: [p, S, Cs] blocks -> rows [S, C]
+    blocks = torch.randn(p, S, Cs, device="cuda", generator=g).to(BF16)
+    rows = torch.full((S, C + 8), float("nan"), device="cuda", dtype=BF16)[:, :C]
+    H.gather_col_blocks(blocks, rows)
+    assert torch.equal(rows, blocks.permute(1, 0, 2).reshape(S, C))
