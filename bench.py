@@ -40,7 +40,7 @@ WORKLOADS = {
     "cfg4": dict(desc="OmniVideo2-A14B T2V 81f 1280x720 50 steps bf16, both experts resident", model="A14B",
                  latent=(16, 21, 90, 160), frames=81, steps=50, text_len=6144, n_text=20, n_vlm=60, n_null=126,
                  visual=False),
-    "cfg5": dict(desc="OmniVideo2-A14B V2V 81f 1280x720 40 steps, e4m3 linear layers + bf16 attention "
+    "cfg5": dict(desc="OmniVideo2-A14B V2V 81f 1280x720 40 steps, e4m3 linear layers + int8 Q K^T, "
                       "both experts resident", model="A14B", latent=(16, 21, 90, 160), frames=81, steps=40,
                  text_len=6144, n_text=550, n_vlm=700, n_null=126, visual=True, precision="fp8"),
     "cfg1": dict(desc="OmniVideo2-1.3B T2V 17f 256x256 20 steps (bf16 on GPU)", model="1.3B", latent=(16, 5, 32, 32),
@@ -126,6 +126,47 @@ def self_launch(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+_LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+               "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+               "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE",
+               "TORCHELASTIC_ERROR_FILE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "OVD_LIB_PATH_UNUSED")
+
+
+def companion_run(workload, n, extra, limit_s=600):
+    """After the headline measurement, on rank 0 alone (the other ranks have exited and this process has
+    released its buffers): the sequence-parallel configuration of the metric - one `workload` video over
+    all n GPUs, RCCL all-to-alls - as a separate job of n fresh ranks (this script again, self-launched),
+    bounded in time and isolated from the headline line: whatever happens to it, that line is printed."""
+    import signal
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--workload", workload, "--parallel", "sp",
+           "--steps", "2", "--warmup", "1", "--no-vae", "--no-cpu-baseline", "--companion", "off"] + extra
+    t0 = time.time()
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                start_new_session=True)
+        try:
+            so, se = proc.communicate(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.communicate()
+            return {"error": f"killed after {limit_s} s"}
+        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or not lines:
+            return {"error": f"exit status {proc.returncode}", "stderr_tail": se[-600:]}
+        r = json.loads(lines[-1])
+        keep = ("value", "unit", "n_gpus", "ms_per_step", "scaling", "dtype", "context_encode_s_per_video",
+                "step_tflops", "roofline")
+        res = {k: r.get(k) for k in keep}
+        res["config"] = {k: r["config"].get(k) for k in ("workload", "parallelism", "experts_resident",
+                                                          "timed_schedule_steps", "graph_replay")}
+        res["wall_s"] = round(time.time() - t0, 1)
+        return res
+    except Exception as err:          # noqa: BLE001 - the headline line must survive anything here
+        return {"error": f"{type(err).__name__}: {err}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +183,11 @@ def main():
                     help="with --gpus N > 1: dp = one video per GPU (no data-path collective); sp = one video "
                          "over all N GPUs, Ulysses sequence parallelism; auto = sp for the A14B workloads "
                          "(40 heads), dp for the 1.3B ones (12 heads do not divide by 8)")
+    ap.add_argument("--companion", default="auto",
+                    help="with --gpus N > 1 and the default (data-parallel 1.3B) workload, rank 0 afterwards also runs "
+                         "the sequence-parallel configuration of the metric (cfg4: A14B 81f 720p over all N GPUs, "
+                         "when 40 heads divide by N) as a separate bounded job and reports it under "
+                         "'sequence_parallel_companion'; 'off' disables, a workload name selects another one")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: every rank uses cuda:0 and the gloo backend, to exercise the "
                          "multi-rank control flow on a one-GPU box (numbers are meaningless)")
@@ -275,8 +321,12 @@ def main():
                     traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
                     tsrc = f"offline rocprofv3 --pmc passes at this shape, profiles/{name} (not measured by this run)"
                     break
-            roof = {"bound": "mfma", "kernel": "attn_pipe_kernel_w8 (self-attention)", "achieved": round(ach, 1),
-                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+            int8_attn = eng.attention == "int8"
+            # int8 Q K^T runs at twice the bf16 rate, P V at the bf16 rate, half of the FLOPs each:
+            # the launch's matrix-time roof is 1 / (0.5 / 5000 + 0.5 / 2500) = 3333 TFLOP/s
+            peak = 1.0 / (0.5 / (2 * PEAK_BF16_TFLOPS) + 0.5 / PEAK_BF16_TFLOPS) if int8_attn else PEAK_BF16_TFLOPS
+            roof = {"bound": "mfma", "kernel": ("attn_i8_kernel_w8" if int8_attn else "attn_pipe_kernel_w8") + " (self-attention)",
+                    "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": tsrc, "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4),
                     "flop_per_launch": flops_launch}
 
@@ -330,7 +380,7 @@ def main():
             "metric": "denoised frames/sec (whole node)", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "strong" if sp else "weak", "vs_baseline": None,
-            "dtype": "bf16" if precision == "bf16" else "fp8 (e4m3 linear layers, bf16 attention, fp32 residual stream)",
+            "dtype": "bf16" if precision == "bf16" else "fp8 (e4m3 linear layers, int8 Q K^T in self-attention with bf16 P V, fp32 residual stream)",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "linear_precision": precision, "latent": list(wl["latent"]), "tokens": seq_len,
                        "context_len": wl["text_len"], "context_keys_read": cache.k_len, "sampling_steps": wl["steps"], "guide_scale": 3.0,
@@ -355,10 +405,27 @@ def main():
             out["value_with_vae_decode"] = round(videos * wl["frames"] / (wl["steps"] * ms_step * 1e-3 + ctx_s + vae_s), 4)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, wl, args.cpu_threads)
-        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    comp = args.companion
+    if comp == "auto":
+        comp = "cfg4" if (world > 1 and not sp and args.workload == "cfg2" and not args.rehearse_on_one_gpu) else "off"
+    if rank == 0:
+        if comp != "off" and world > 1:
+            if syn.dit_config(WORKLOADS[comp]["model"])["num_heads"] % world == 0:
+                # free this process's buffers; the other ranks leave on their own once the group is gone
+                eng = Lw = cache = roof = None                     # noqa: F841 - drop every reference to device buffers
+                del loop, experts, model, pairs
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                time.sleep(5.0)
+                out["sequence_parallel_companion"] = companion_run(
+                    comp, world, ["--rehearse-on-one-gpu"] if args.rehearse_on_one_gpu else [])
+            else:
+                out["sequence_parallel_companion"] = {"skipped": f"{comp}: heads do not divide by {world} ranks"}
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -260,6 +260,26 @@ int ovd_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, float a_sc
                  const float* w_scale, const void* bias, void* out, int64_t ldo, const float* gate, float out_scale,
                  int M, int N, int K, int epilogue, void* stream);
 
+/* Reduced-precision self-attention of the same mode: Q K^T on int8 operands (v_mfma_i32_32x32x32_i8, half
+ * the matrix time of the bf16 product), softmax in fp32, P and V in bf16 as in ovd_flash_attn_fwd_bf16.
+ * No reference counterpart (the reference's attention is flash-attn in bf16, attention.py:96-130); checked
+ * against this library's bf16 attention and the exact-softmax oracle at a stated tolerance.
+ *
+ * ovd_quant_heads_i8: x bf16 [B, L, N, 128] (token stride ldx, batch stride x_bs, elements) -> q int8 of the
+ * same shape (ldq, q_bs) and one fp32 scale per rows_per_scale rows and head, x ~ q * scale with
+ * scale = absmax / 127 of the block (1 for an all-zero block), q = rint(x * (127 / absmax)):
+ *   rows_per_scale = 1  (queries): scale [B, L, N];
+ *   rows_per_scale = 64 (keys, one scale per 64-key tile): scale [B, ceil(L / 64), N].
+ * ovd_flash_attn_qk8_fwd_bf16: q8 / q_scale and k8 / k_scale in those two forms, v and out bf16; strides in
+ * elements; keys >= k_len masked; workspace as in ovd_flash_attn_ws_fwd_bf16 (NULL = none). */
+int ovd_quant_heads_i8(const uint16_t* x, int64_t ldx, int64_t x_bs, int8_t* q, int64_t ldq, int64_t q_bs, float* scale,
+                       int B, int L, int N, int head_dim, int rows_per_scale, void* stream);
+int ovd_flash_attn_qk8_fwd_bf16(const int8_t* q8, const float* q_scale, const int8_t* k8, const float* k_scale,
+                                const uint16_t* v, uint16_t* out, int B, int Lq, int Lk, int N, int head_dim, int k_len,
+                                int64_t q_ld, int64_t k_ld, int64_t v_ld, int64_t o_ld, int64_t q_bs, int64_t k_bs,
+                                int64_t v_bs, int64_t o_bs, float softmax_scale, void* workspace,
+                                int64_t workspace_bytes, void* stream);
+
 /* Source-video frames -> VAE encoder input, the device half of transform_frames_to_tensor
  * (tools/inference/generate_omni_v2v.py:306-343: CenterCrop, Resize on a PIL image = Pillow's 8-bit
  * bilinear resample, ToTensor, Normalize).  frames [T,H,W,3] uint8; the crop window (top, left,

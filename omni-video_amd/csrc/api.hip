@@ -27,6 +27,9 @@ int ovd_impl_gemm_bf16(const bf16_t*, long, const bf16_t*, long, const bf16_t*, 
 int ovd_impl_attn_fwd(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, long, long,
                       long, long, long, long, long, long, float, int, void*, long, hipStream_t);
 long ovd_impl_attn_workspace_bytes(int, int, int, int);
+int ovd_impl_quant_heads_i8(const bf16_t*, long, long, int8_t*, long, long, float*, int, int, int, int, int, hipStream_t);
+int ovd_impl_attn_i8_fwd(const int8_t*, const float*, const int8_t*, const float*, const bf16_t*, bf16_t*, int, int, int,
+                         int, int, int, long, long, long, long, long, long, long, long, float, void*, long, hipStream_t);
 int ovd_impl_attn_fwd_static(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, long,
                              long, long, long, long, long, long, long, float, int, hipStream_t);
 int ovd_impl_to_uint8(const float*, uint8_t*, long, long, int, long, float, float, hipStream_t);
@@ -166,6 +169,24 @@ int ovd_flash_attn_static_fwd_bf16(const uint16_t* q, const uint16_t* k, const u
     NONNULL(q); NONNULL(k); NONNULL(v); NONNULL(out);
     return ovd_impl_attn_fwd_static(q, k, v, out, B, Lq, Lk, N, head_dim, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs,
                                     v_bs, o_bs, softmax_scale, last_key_copies, ST(stream));
+}
+
+int ovd_quant_heads_i8(const uint16_t* x, int64_t ldx, int64_t x_bs, int8_t* q, int64_t ldq, int64_t q_bs, float* scale,
+                       int B, int L, int N, int head_dim, int rows_per_scale, void* stream) {
+    NONNULL(x); NONNULL(q); NONNULL(scale);
+    return ovd_impl_quant_heads_i8(x, ldx, x_bs, q, ldq, q_bs, scale, B, L, N, head_dim, rows_per_scale, ST(stream));
+}
+
+int ovd_flash_attn_qk8_fwd_bf16(const int8_t* q8, const float* q_scale, const int8_t* k8, const float* k_scale,
+                                const uint16_t* v, uint16_t* out, int B, int Lq, int Lk, int N, int head_dim, int k_len,
+                                int64_t q_ld, int64_t k_ld, int64_t v_ld, int64_t o_ld, int64_t q_bs, int64_t k_bs,
+                                int64_t v_bs, int64_t o_bs, float softmax_scale, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    NONNULL(q8); NONNULL(q_scale); NONNULL(k8); NONNULL(k_scale); NONNULL(v); NONNULL(out);
+    OVD_REQUIRE(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0),
+                "attention: workspace_bytes=%lld without a workspace", (long long)workspace_bytes);
+    return ovd_impl_attn_i8_fwd(q8, q_scale, k8, k_scale, v, out, B, Lq, Lk, N, head_dim, k_len, q_ld, k_ld, v_ld, o_ld,
+                                q_bs, k_bs, v_bs, o_bs, softmax_scale, workspace, workspace_bytes, ST(stream));
 }
 
 int ovd_patchify(const void* lat, int lat_is_bf16, uint16_t* rows, int Cin, int T, int H, int W, int pt, int ph,

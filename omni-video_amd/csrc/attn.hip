@@ -51,6 +51,17 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
 
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+// int8 K tile: rows of 128 bytes (8 chunks); chunk c of row r sits at c ^ ((r >> 1) & 7), which spreads every
+// 16-lane group of a ds_read_b128 fragment read over 16 distinct 16-byte bank slots
+__device__ __forceinline__ int k8_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+// The int8 score accumulators start at the bit pattern of 1.5 * 2^23: adding an integer |s| < 2^22 to that
+// pattern gives the bit pattern of the float 12582912 + s, so the finished int32 accumulator IS a float and
+// no conversion instruction is spent per score (sum of 128 products of int8: |s| <= 128 * 127^2 < 2^22).
+constexpr int I8_MAGIC_BITS = 0x4B400000;
+constexpr float I8_MAGIC = 12582912.0f;
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 256 + ((chunk ^ ((row & 3) << 2)) << 4); }
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
@@ -124,16 +135,30 @@ __device__ __forceinline__ void stage_next(Stream& s, char* dst_wave) {
     s.row += s.tile;
 }
 
+// int8 K tile: 64 rows x 128 bytes; one wave instruction covers 8 rows
+template <int NW>
+__device__ __forceinline__ void stage_next_k8(Stream& s, char* dst_wave) {
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+        const unsigned ro = min(s.row + i * s.pass, s.last);
+        __builtin_amdgcn_global_load_lds(s.base + ro + s.chunk, (lds_ptr)(dst_wave + i * NW * 1024), 16, 0, 0);
+    }
+    s.row += s.tile;
+}
+
 // c0/c1: scores of the current tile; mx = their row maximum (scaled, whole wave), need = some
 // row's maximum outgrew the running one.  n0/n1 receive the scores of the next tile (HAS_NEXT),
 // read from sk_next; V of the current tile is in sv_cur.  The K tile after next and the next
 // V tile are put in flight from inside the first two k-steps.
-template <int NW, bool HAS_NEXT, bool MASK_NEXT>
+// I8: Q and K are int8 with the scores' scale folded into sc_cur / sc_next (scale_log2 * the query's scale *
+// the key tile's scale; bf16: both are scale_log2); qf then holds 4 fragments of 16 bytes in its first 16
+// registers, the K tile has 128-byte rows, and a score register holds the float 12582912 + s.
+template <int NW, bool I8, bool HAS_NEXT, bool MASK_NEXT>
 __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)[8], float& m_c, float& l_run,
                                           const f32x16& c0, const f32x16& c1, f32x16& n0, f32x16& n1,
                                           float& mx, bool& need, const char* sk_next, const char* sv_cur,
                                           Stream& ks_, char* k_dst, Stream& vs_, char* v_dst, int key0_next,
-                                          int k_len, float tail_bias, float scale_log2, int lane) {
+                                          int k_len, float tail_bias, float sc_cur, float sc_next, int lane) {
     const int l31 = lane & 31, hi = lane >> 5;
     if (need) {
         const float m_new = __builtin_fmaxf(m_c, mx);
@@ -148,8 +173,11 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
     // ---- S^T of the next tile (MFMA) beside exp / sum / pack of the current one (VALU)
     if (HAS_NEXT) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) n0[j] = n1[j] = 0.f;
+        for (int j = 0; j < 16; ++j) n0[j] = n1[j] = I8 ? __int_as_float(I8_MAGIC_BITS) : 0.f;
     }
+    // p = exp2(score * scale_log2 - m_c); with int8 scores the register holds 12582912 + score
+    const float scale_log2 = sc_cur;
+    const float m_sub = I8 ? __builtin_fmaf(sc_cur, I8_MAGIC, m_c) : m_c;
     float rs0 = 0.f, rs1 = 0.f;
     uint32_t pw[16];     // packed bf16 pairs of P: word i = scores 2i, 2i+1 (score i<16 -> c0[i], else c1[i-16])
     // exp / sum / pack of two adjacent scores; the empty asm pins the result inside the
@@ -158,8 +186,8 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
     do {                                                                                           \
         const f32x16& c_ = (i) < 8 ? c0 : c1;                                                      \
         const int r_ = ((i) & 7) * 2;                                                              \
-        const float pa_ = __builtin_amdgcn_exp2f(__builtin_fmaf(c_[r_], scale_log2, -m_c));        \
-        const float pb_ = __builtin_amdgcn_exp2f(__builtin_fmaf(c_[r_ + 1], scale_log2, -m_c));    \
+        const float pa_ = __builtin_amdgcn_exp2f(__builtin_fmaf(c_[r_], scale_log2, -m_sub));      \
+        const float pb_ = __builtin_amdgcn_exp2f(__builtin_fmaf(c_[r_ + 1], scale_log2, -m_sub));  \
         rs0 += pa_;                                                                                \
         rs1 += pb_;                                                                                \
         pw[i] = pack_bf2(pa_, pb_);                                                                \
@@ -182,28 +210,58 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
     // {2 LDS reads, 2 MFMAs, its share of the softmax} together so that register life times
     // stay short and the vector work sits in the MFMA shadows.  24 of the 32 scores are
     // finished here (4 / 2 per k-step), the last 8 beside the first P V products.
-    bf16x8 kf[2][2];
-    if (HAS_NEXT) {
-        kf[0][0] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(l31, hi));
-        kf[0][1] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(32 + l31, hi));
-    }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    if constexpr (!I8) {
+        bf16x8 kf[2][2];
         if (HAS_NEXT) {
-            if (ks < 7) {
-                kf[(ks + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(l31, 2 * ks + 2 + hi));
-                kf[(ks + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(32 + l31, 2 * ks + 2 + hi));
-            }
-            n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][0], qf[ks], n0, 0, 0, 0);
-            n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][1], qf[ks], n1, 0, 0, 0);
+            kf[0][0] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(l31, hi));
+            kf[0][1] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(32 + l31, hi));
         }
-        const int pi = 3 * (ks >> 1) + 2 * (ks & 1);      // first pair of this k-step: 0,2,3,5,6,8,9,11
-        SOFTMAX_PAIR(pi);
-        if (!(ks & 1)) SOFTMAX_PAIR(pi + 1);
-        if (ks == 0) stage_next<NW>(ks_, k_dst);
-        if (ks == 1) stage_next<NW>(vs_, v_dst);
-        if (ks == 7) READ_V(0, vf[0]);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (HAS_NEXT) {
+                if (ks < 7) {
+                    kf[(ks + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(l31, 2 * ks + 2 + hi));
+                    kf[(ks + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(sk_next + k_off(32 + l31, 2 * ks + 2 + hi));
+                }
+                n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][0], qf[ks], n0, 0, 0, 0);
+                n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][1], qf[ks], n1, 0, 0, 0);
+            }
+            const int pi = 3 * (ks >> 1) + 2 * (ks & 1);      // first pair of this k-step: 0,2,3,5,6,8,9,11
+            SOFTMAX_PAIR(pi);
+            if (!(ks & 1)) SOFTMAX_PAIR(pi + 1);
+            if (ks == 0) stage_next<NW>(ks_, k_dst);
+            if (ks == 1) stage_next<NW>(vs_, v_dst);
+            if (ks == 7) READ_V(0, vf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // int8: 4 k-steps of 32 dims, two v_mfma_i32_32x32x32_i8 each (half the matrix time of the bf16 form);
+        // 8 of the 16 score pairs are finished here, the rest beside the P V products
+        i32x4 kf[2][2];
+        const i32x4* q8 = reinterpret_cast<const i32x4*>(&qf[0]);
+        if (HAS_NEXT) {
+            kf[0][0] = *reinterpret_cast<const i32x4*>(sk_next + k8_off(l31, hi));
+            kf[0][1] = *reinterpret_cast<const i32x4*>(sk_next + k8_off(32 + l31, hi));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (HAS_NEXT) {
+                if (ks < 3) {
+                    kf[(ks + 1) & 1][0] = *reinterpret_cast<const i32x4*>(sk_next + k8_off(l31, 2 * ks + 2 + hi));
+                    kf[(ks + 1) & 1][1] = *reinterpret_cast<const i32x4*>(sk_next + k8_off(32 + l31, 2 * ks + 2 + hi));
+                }
+                n0 = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                                                    kf[ks & 1][0], q8[ks], __builtin_bit_cast(i32x16, n0), 0, 0, 0));
+                n1 = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                                                    kf[ks & 1][1], q8[ks], __builtin_bit_cast(i32x16, n1), 0, 0, 0));
+            }
+            SOFTMAX_PAIR(2 * ks);
+            SOFTMAX_PAIR(2 * ks + 1);
+            if (ks == 0) stage_next_k8<NW>(ks_, k_dst);
+            if (ks == 1) stage_next<NW>(vs_, v_dst);
+            if (ks == 3) READ_V(0, vf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (HAS_NEXT) mask_scores<MASK_NEXT>(n0, n1, key0_next, k_len, tail_bias, hi);
 
@@ -218,16 +276,21 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
 #pragma unroll
         for (int db = 0; db < 4; ++db)
             o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st & 1][db], pfrag, o_acc[db], 0, 0, 0);
-        if (st < 2) {
+        if (I8) {                 // pairs 8-10, 11-13, 14-15 (each four are packed before the step that multiplies them)
+            if (st == 0) { SOFTMAX_PAIR(8); SOFTMAX_PAIR(9); SOFTMAX_PAIR(10); }
+            if (st == 1) { SOFTMAX_PAIR(11); SOFTMAX_PAIR(12); SOFTMAX_PAIR(13); }
+            if (st == 2) { SOFTMAX_PAIR(14); SOFTMAX_PAIR(15); }
+        } else if (st < 2) {
             SOFTMAX_PAIR(12 + 2 * st);
             SOFTMAX_PAIR(13 + 2 * st);
-        } else if (HAS_NEXT) {
+        }
+        if (st >= 2 && HAS_NEXT) {
             const f32x16& n = st == 2 ? n0 : n1;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) nmx = max3(nmx, n[r], n[r + 1]);
             asm volatile("" : "+v"(nmx));
             if (st == 3) {
-                mx = half_max(nmx) * scale_log2;
+                mx = (I8 ? half_max(nmx) - I8_MAGIC : half_max(nmx)) * sc_next;
                 need = __any(mx > m_c + RESCALE_THR);
             }
         }
@@ -240,12 +303,19 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
 
 constexpr int WS_VALUES = 66;      // per lane of a split workgroup: 64 accumulators, row maximum, row sum
 
-template <int NW>
+// I8: Q and K point at int8 tensors of the same [B, L, N, 128] shape (strides in elements = bytes) with
+// q_scale [B, Lq, N] (one per token and head) and k_scale [B, ceil(Lk / 64), N] (one per 64-key tile and
+// head): q ~ q8 * q_scale, k ~ k8 * k_scale.
+template <int NW, bool I8>
 __device__ __forceinline__ void
-attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+attn_fwd_pipe(const void* __restrict__ Qv, const void* __restrict__ Kv, const bf16_t* __restrict__ V,
               bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,
               long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias, int n_qblocks,
-              int n_heads, int n_batch, float* __restrict__ ws, int n_split, int k_split) {
+              int n_heads, int n_batch, float* __restrict__ ws, int n_split, int k_split,
+              const float* __restrict__ q_scale, const float* __restrict__ k_scale) {
+    constexpr int ESZ = I8 ? 1 : 2;         // bytes per Q / K element
+    const char* Q = reinterpret_cast<const char*>(Qv);
+    const char* K = reinterpret_cast<const char*>(Kv);
     extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2] | V[2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -290,18 +360,30 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
         k_len -= k_split;
         Lk -= k_split;
     }
-    const bf16_t* Qb = Q + b * q_bs + (long)head * HD;
-    const bf16_t* Kb = K + b * k_bs + (long)head * HD + (long)k_begin * k_ld;
+    const char* Qb = Q + (b * q_bs + (long)head * HD) * ESZ;
+    const char* Kb = K + (b * k_bs + (long)head * HD + (long)k_begin * k_ld) * ESZ;
     const bf16_t* Vb = V + b * v_bs + (long)head * HD + (long)k_begin * v_ld;
 
     bf16x8 qf[8];
+    float sq = scale_log2;                  // int8: scale_log2 * this lane's query scale
+    const float* ksc = nullptr;             // int8: scales of this (batch, head)'s key tiles, tile stride n_heads
     {
         int qr = q0 + l31;
         qr = qr < Lq ? qr : Lq - 1;
-        const bf16_t* qp = Qb + (long)qr * q_ld + 8 * hi;
+        if constexpr (I8) {
+            const char* qp = Qb + (long)qr * q_ld + 16 * hi;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+            sq *= q_scale[((long)b * Lq + qr) * n_heads + head];
+            ksc = k_scale + ((long)b * ((Lk + (half == 1 ? k_split : 0) + BKV - 1) / BKV) + k_begin / BKV) * n_heads + head;
+        } else {
+            const char* qp = Qb + ((long)qr * q_ld + 8 * hi) * 2;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+        }
     }
+    // scale of tile t's scores (bf16: scale_log2 for every tile)
+    auto tile_scale = [&](int t) -> float { return I8 ? sq * ksc[(long)t * n_heads] : scale_log2; };
     f32x16 o_acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -316,23 +398,37 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
     Stream kst, vst;
     {
         const int r = wave * 4 + (lane >> 4), p = lane & 15;
-        kst.base = reinterpret_cast<const char*>(Kb);
+        kst.base = Kb;
         vst.base = reinterpret_cast<const char*>(Vb);
-        kst.row = (unsigned)r * (unsigned)k_ld * 2u;
         vst.row = (unsigned)r * (unsigned)v_ld * 2u;
-        kst.chunk = (unsigned)((p ^ (r & 15)) << 4);
         vst.chunk = (unsigned)((p ^ ((r & 3) << 2)) << 4);
-        kst.last = (unsigned)(Lk - 1) * (unsigned)k_ld * 2u;
         vst.last = (unsigned)(Lk - 1) * (unsigned)v_ld * 2u;
-        kst.pass = 4u * NW * (unsigned)k_ld * 2u;
         vst.pass = 4u * NW * (unsigned)v_ld * 2u;
-        kst.tile = (unsigned)BKV * (unsigned)k_ld * 2u;
         vst.tile = (unsigned)BKV * (unsigned)v_ld * 2u;
+        if constexpr (I8) {        // 128-byte rows: a wave instruction covers 8 rows, 8 lanes each
+            const int r8 = wave * 8 + (lane >> 3), p8 = lane & 7;
+            kst.row = (unsigned)r8 * (unsigned)k_ld;
+            kst.chunk = (unsigned)((p8 ^ ((r8 >> 1) & 7)) << 4);
+            kst.last = (unsigned)(Lk - 1) * (unsigned)k_ld;
+            kst.pass = 8u * NW * (unsigned)k_ld;
+            kst.tile = (unsigned)BKV * (unsigned)k_ld;
+        } else {
+            kst.row = (unsigned)r * (unsigned)k_ld * 2u;
+            kst.chunk = (unsigned)((p ^ (r & 15)) << 4);
+            kst.last = (unsigned)(Lk - 1) * (unsigned)k_ld * 2u;
+            kst.pass = 4u * NW * (unsigned)k_ld * 2u;
+            kst.tile = (unsigned)BKV * (unsigned)k_ld * 2u;
+        }
     }
     char* const wave_lds = smem + wave * 1024;
-    stage_next<NW>(kst, wave_lds);                                   // K(0) -> K buffer 0
+    auto stage_k = [&](char* dst) {
+        if constexpr (I8) stage_next_k8<NW>(kst, dst);
+        else stage_next<NW>(kst, dst);
+    };
+    stage_k(wave_lds);                                               // K(0) -> K buffer 0
     stage_next<NW>(vst, wave_lds + 2 * KV_TILE_BYTES);               // V(0) -> V buffer 0
-    stage_next<NW>(kst, wave_lds + KV_TILE_BYTES);                   // K(1) -> K buffer 1
+    stage_k(wave_lds + KV_TILE_BYTES);                               // K(1) -> K buffer 1
+    float sc_c = tile_scale(0), sc_n = sc_c;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -340,17 +436,31 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
     float mx;
     bool need;
     {   // scores of tile 0
+        if constexpr (I8) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a0[j] = a1[j] = 0.f;
+            for (int j = 0; j < 16; ++j) a0[j] = a1[j] = __int_as_float(I8_MAGIC_BITS);
+            const i32x4* q8 = reinterpret_cast<const i32x4*>(&qf[0]);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(smem + k_off(l31, 2 * ks + hi));
-            const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(smem + k_off(32 + l31, 2 * ks + hi));
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], a1, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const i32x4 kf0 = *reinterpret_cast<const i32x4*>(smem + k8_off(l31, 2 * ks + hi));
+                const i32x4 kf1 = *reinterpret_cast<const i32x4*>(smem + k8_off(32 + l31, 2 * ks + hi));
+                a0 = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(kf0, q8[ks], __builtin_bit_cast(i32x16, a0), 0, 0, 0));
+                a1 = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(kf1, q8[ks], __builtin_bit_cast(i32x16, a1), 0, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a0[j] = a1[j] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(smem + k_off(l31, 2 * ks + hi));
+                const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(smem + k_off(32 + l31, 2 * ks + hi));
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], a1, 0, 0, 0);
+            }
         }
         if (nt == 1 && partial) mask_scores<true>(a0, a1, 0, k_len, tail_bias, hi);
-        mx = half_max(lane_max32(a0, a1)) * scale_log2;
+        const float raw = half_max(lane_max32(a0, a1));
+        mx = (I8 ? raw - I8_MAGIC : raw) * sc_c;
         need = __any(mx > m_c + RESCALE_THR);
     }
     __syncthreads();    // every wave is done with K(0) before K(2) overwrites it
@@ -360,12 +470,14 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
 #define PIPE_STEP(HAS_NEXT, MASK_NEXT, C0, C1, N0, N1, t)                                                \
     do {                                                                                                 \
         const int t_ = (t);                                                                              \
-        pipe_step<NW, HAS_NEXT, MASK_NEXT>(o_acc, qf, m_c, l_run, C0, C1, N0, N1, mx, need,              \
-                                           smem + ((t_ + 1) & 1) * KV_TILE_BYTES,                        \
-                                           smem + (2 + (t_ & 1)) * KV_TILE_BYTES, kst,                   \
-                                           wave_lds + (t_ & 1) * KV_TILE_BYTES, vst,                     \
-                                           wave_lds + (2 + ((t_ + 1) & 1)) * KV_TILE_BYTES,              \
-                                           (t_ + 1) * BKV, k_len, tail_bias, scale_log2, lane);          \
+        if (I8 && HAS_NEXT) sc_n = tile_scale(t_ + 1);                                                   \
+        pipe_step<NW, I8, HAS_NEXT, MASK_NEXT>(o_acc, qf, m_c, l_run, C0, C1, N0, N1, mx, need,          \
+                                               smem + ((t_ + 1) & 1) * KV_TILE_BYTES,                    \
+                                               smem + (2 + (t_ & 1)) * KV_TILE_BYTES, kst,               \
+                                               wave_lds + (t_ & 1) * KV_TILE_BYTES, vst,                 \
+                                               wave_lds + (2 + ((t_ + 1) & 1)) * KV_TILE_BYTES,          \
+                                               (t_ + 1) * BKV, k_len, tail_bias, sc_c, sc_n, lane);      \
+        sc_c = sc_n;                                                                                     \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
         __syncthreads();                                                                                 \
     } while (0)
@@ -437,8 +549,19 @@ attn_fwd_pipe(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const 
         bf16_t* __restrict__ O, int Lq, int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld,   \
         long q_bs, long k_bs, long v_bs, long o_bs, float scale_log2, float tail_bias, int n_qblocks,    \
         int n_heads, int n_batch, float* __restrict__ ws, int n_split, int k_split) {                    \
-        attn_fwd_pipe<NW>(Q, K, V, O, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs,     \
-                          scale_log2, tail_bias, n_qblocks, n_heads, n_batch, ws, n_split, k_split);     \
+        attn_fwd_pipe<NW, false>(Q, K, V, O, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs,    \
+                                 o_bs, scale_log2, tail_bias, n_qblocks, n_heads, n_batch, ws, n_split,  \
+                                 k_split, nullptr, nullptr);                                             \
+    }                                                                                                    \
+    __global__ void __launch_bounds__(64 * NW, 2) attn_i8_kernel_w##NW(                                  \
+        const int8_t* __restrict__ Q, const float* __restrict__ q_scale, const int8_t* __restrict__ K,  \
+        const float* __restrict__ k_scale, const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int Lq, \
+        int Lk, int k_len, long q_ld, long k_ld, long v_ld, long o_ld, long q_bs, long k_bs, long v_bs,  \
+        long o_bs, float scale_log2, int n_qblocks, int n_heads, int n_batch, float* __restrict__ ws,    \
+        int n_split, int k_split) {                                                                      \
+        attn_fwd_pipe<NW, true>(Q, K, V, O, Lq, Lk, k_len, q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs,     \
+                                o_bs, scale_log2, 0.f, n_qblocks, n_heads, n_batch, ws, n_split,         \
+                                k_split, q_scale, k_scale);                                              \
     }
 ATTN_KERNEL(4)
 ATTN_KERNEL(8)
@@ -480,6 +603,70 @@ __global__ void __launch_bounds__(64) attn_merge_kernel(const float* __restrict_
             w.y = pack_bf2(y[2], y[3]);
             *reinterpret_cast<uint2*>(op + db * 32 + 8 * g4) = w;
         }
+}
+
+// bf16 x [B, L, N, 128] -> int8 q of the same shape and one scale per (RPS rows, head): x ~ q * scale,
+// scale = absmax / 127 over the RPS x 128 block (1 when the block is all zero), q = rint(x * (127 / absmax)).
+// One block = 64 rows of one (batch, head); thread t holds 32 consecutive dims of row t / 4.
+template <int RPS>
+__global__ void __launch_bounds__(256) quant_heads_i8_kernel(const bf16_t* __restrict__ x, long ldx, long x_bs,
+                                                             int8_t* __restrict__ q, long ldq, long q_bs,
+                                                             float* __restrict__ scale, int L, int N) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, row = blockIdx.x * 64 + (tid >> 2), quarter = tid & 3;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const bool live = row < L;
+    uint4 raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) raw[i] = make_uint4(0, 0, 0, 0);
+    if (live) {
+        const uint4* src = reinterpret_cast<const uint4*>(x + b * x_bs + (long)row * ldx + head * HD + quarter * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw[i] = src[i];
+    }
+    float v[32];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t u[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[i * 8 + 2 * j] = bf2f(u[j] & 0xffff);
+            v[i * 8 + 2 * j + 1] = bf2f(u[j] >> 16);
+            mx = __builtin_fmaxf(mx, __builtin_fmaxf(fabsf(v[i * 8 + 2 * j]), fabsf(v[i * 8 + 2 * j + 1])));
+        }
+    }
+    mx = __builtin_fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = __builtin_fmaxf(mx, __shfl_xor(mx, 2, 64));
+    if (RPS > 1) {
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        mx = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+    }
+    const float inv = mx > 0.f ? 127.0f / mx : 0.f;
+    if (RPS > 1) {
+        if (tid == 0) scale[((long)b * gridDim.x + blockIdx.x) * N + head] = mx > 0.f ? mx / 127.0f : 1.f;
+    } else if (live && quarter == 0) {
+        scale[((long)b * L + row) * N + head] = mx > 0.f ? mx / 127.0f : 1.f;
+    }
+    if (!live) return;
+    uint32_t o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int qi = __float2int_rn(v[i * 4 + j] * inv);
+            qi = qi > 127 ? 127 : (qi < -127 ? -127 : qi);
+            w |= (uint32_t)(qi & 0xff) << (8 * j);
+        }
+        o[i] = w;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(q + b * q_bs + (long)row * ldq + head * HD + quarter * 32);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 }  // namespace
@@ -601,5 +788,73 @@ int ovd_impl_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
     if (waves == 8) ATTN_CASE(attn_pipe_kernel_w8, 8) else ATTN_CASE(attn_pipe_kernel_w4, 4)
 #undef ATTN_CASE
     OVD_CHECK_LAUNCH("attn_fwd");
+    return 0;
+}
+
+// x [B, L, N, 128] bf16 -> int8 + scales; rows_per_scale 1 (queries: one scale per token and head) or
+// 64 (keys: one per 64-key tile and head; scale [B, ceil(L / 64), N])
+int ovd_impl_quant_heads_i8(const bf16_t* x, long ldx, long x_bs, int8_t* q, long ldq, long q_bs, float* scale, int B,
+                            int L, int N, int D, int rows_per_scale, hipStream_t st) {
+    OVD_REQUIRE(D == HD, "quant_heads_i8: head_dim %d not supported (only 128)", D);
+    OVD_REQUIRE(B > 0 && L > 0 && N > 0 && N <= 65535 && B <= 65535, "quant_heads_i8: bad shape B=%d L=%d N=%d", B, L, N);
+    OVD_REQUIRE(rows_per_scale == 1 || rows_per_scale == BKV, "quant_heads_i8: rows_per_scale must be 1 or %d", BKV);
+    OVD_REQUIRE(ldx % 8 == 0 && x_bs % 8 == 0 && ldq % 16 == 0 && q_bs % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(q) % 16 == 0,
+                "quant_heads_i8: rows must keep 16-byte alignment");
+    OVD_REQUIRE(ldx >= (long)N * D && ldq >= (long)N * D, "quant_heads_i8: token stride shorter than N*D");
+    dim3 grid(ceil_div(L, 64), N, B), blk(256);
+    if (rows_per_scale == 1)
+        hipLaunchKernelGGL(quant_heads_i8_kernel<1>, grid, blk, 0, st, x, ldx, x_bs, q, ldq, q_bs, scale, L, N);
+    else
+        hipLaunchKernelGGL(quant_heads_i8_kernel<BKV>, grid, blk, 0, st, x, ldx, x_bs, q, ldq, q_bs, scale, L, N);
+    OVD_CHECK_LAUNCH("quant_heads_i8");
+    return 0;
+}
+
+// Attention with Q K^T on int8 operands (v_mfma_i32_32x32x32_i8, half the matrix time of the bf16 product);
+// softmax, P and P V as in ovd_impl_attn_fwd.  q8 / k8 and their scales: ovd_impl_quant_heads_i8.
+int ovd_impl_attn_i8_fwd(const int8_t* q8, const float* q_scale, const int8_t* k8, const float* k_scale,
+                         const bf16_t* v, bf16_t* out, int B, int Lq, int Lk, int N, int D, int k_len, long q_ld,
+                         long k_ld, long v_ld, long o_ld, long q_bs, long k_bs, long v_bs, long o_bs,
+                         float softmax_scale, void* workspace, long workspace_bytes, hipStream_t st) {
+    OVD_REQUIRE(D == HD, "attention: head_dim %d not supported (only 128)", D);
+    OVD_REQUIRE(B > 0 && N > 0 && Lq > 0 && Lk > 0, "attention: empty problem B=%d N=%d Lq=%d Lk=%d", B, N, Lq, Lk);
+    OVD_REQUIRE(k_len > 0 && k_len <= Lk, "attention: k_len=%d outside (0, Lk=%d]", k_len, Lk);
+    OVD_REQUIRE(q_ld % 16 == 0 && k_ld % 16 == 0 && v_ld % 8 == 0 && o_ld % 8 == 0 && o_bs % 8 == 0 && q_bs % 16 == 0 &&
+                    k_bs % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(q8) % 16 == 0 && reinterpret_cast<uintptr_t>(k8) % 16 == 0,
+                "attention: token strides and pointers must keep 16-byte alignment");
+    OVD_REQUIRE(q_ld >= (long)N * D && k_ld >= (long)N * D && v_ld >= (long)N * D && o_ld >= (long)N * D,
+                "attention: token stride shorter than N*D");
+    OVD_REQUIRE(softmax_scale > 0.f, "attention: softmax_scale must be positive");
+    OVD_REQUIRE(((long)Lk + 4 * BKV) * (k_ld > 2 * v_ld ? k_ld : 2 * v_ld) < (1L << 32),
+                "attention: one (batch, head) slab of K/V must span less than 4 GiB (Lk=%d)", Lk);
+    const size_t lds = 4 * KV_TILE_BYTES;
+    const float scale_log2 = softmax_scale * 1.4426950408889634f;
+    const bool small = (long)ceil_div(Lq, 256) * N * B < 256 || k_len <= 1024;
+    int n_split = 0, k_split = 0;
+    if (!small && workspace != nullptr) {
+        n_split = attn_split_plan(B, Lq, N, k_len);
+        if ((long)n_split * 8 * 2 * 8 * (WS_VALUES * 64) * (long)sizeof(float) > workspace_bytes) n_split = 0;
+        k_split = (ceil_div(k_len, BKV) / 2) * BKV;
+    }
+#define ATTN_CASE(KERNEL, NW)                                                                              \
+    {                                                                                                      \
+        static OvdLdsLimit lim;                                                                            \
+        if (!lim.ensure(reinterpret_cast<const void*>(&KERNEL), lds))                                      \
+            OVD_FAIL("attention: cannot reserve %zu bytes of LDS", lds);                                    \
+        const int nqb = ceil_div(Lq, 32 * NW);                                                             \
+        OVD_REQUIRE((long)nqb * N * B + 8L * n_split < (1L << 31), "attention: grid too large");           \
+        dim3 grid(nqb * N * B + 8 * n_split), blk(64 * NW);                                                \
+        hipLaunchKernelGGL(KERNEL, grid, blk, lds, st, q8, q_scale, k8, k_scale, v, out, Lq, Lk, k_len,    \
+                           q_ld, k_ld, v_ld, o_ld, q_bs, k_bs, v_bs, o_bs, scale_log2, nqb, N, B,          \
+                           (float*)workspace, n_split, k_split);                                           \
+        if (n_split > 0)                                                                                   \
+            hipLaunchKernelGGL(attn_merge_kernel, dim3(8 * n_split * NW), dim3(64), 0, st,                 \
+                               (const float*)workspace, out, Lq, o_ld, o_bs, nqb, N, B, n_split, NW);      \
+    }
+    if (!small) ATTN_CASE(attn_i8_kernel_w8, 8) else ATTN_CASE(attn_i8_kernel_w4, 4)
+#undef ATTN_CASE
+    OVD_CHECK_LAUNCH("attn_i8_fwd");
     return 0;
 }

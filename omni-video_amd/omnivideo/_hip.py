@@ -29,6 +29,9 @@ SIGNATURES = {
     "ovd_flash_attn_workspace_bytes": [_i, _i, _i, _i],
     "ovd_flash_attn_static_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f,
                                        _p],
+    "ovd_quant_heads_i8": [_p, _l, _l, _p, _l, _l, _p, _i, _i, _i, _i, _i, _p],
+    "ovd_flash_attn_qk8_fwd_bf16": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f,
+                                    _p, _l, _p],
     "ovd_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ovd_time_sinusoid": [_p, _p, _i, _p, _i, _p],
     "ovd_gemv_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -282,6 +285,43 @@ def flash_attn(q, k, v, out, k_len=None, softmax_scale=None, last_key_copies=1, 
     _call("ovd_flash_attn_fwd_bf16", _ptr(q, BF16), _ptr(k, BF16), _ptr(v, BF16), _ptr(out, BF16), B, Lq, Lk, N, D,
           kl, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
           q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream())
+    return out
+
+
+def quant_heads_i8(x, q, scale, rows_per_scale):
+    """x bf16 [B, L, N, 128] (dense heads, strided tokens / batch) -> q int8 [B, L, N, 128], scale fp32
+    [B, L, N] (rows_per_scale 1) or [B, ceil(L / 64), N] (rows_per_scale 64)."""
+    B, L, N, D = x.shape
+    for t in (x, q):
+        if t.dim() != 4 or t.stride(3) != 1 or t.stride(2) != D:
+            raise ValueError("quant_heads_i8: tensors must be [B,L,N,D] with dense (N,D)")
+    if q.shape != x.shape or q.dtype != torch.int8:
+        raise ValueError("quant_heads_i8: q must be int8 of x's shape")
+    want = (B, L if rows_per_scale == 1 else -(-L // rows_per_scale), N)
+    if tuple(scale.shape) != want or scale.dtype != F32 or not scale.is_contiguous():
+        raise ValueError(f"quant_heads_i8: scale must be contiguous fp32 {want}")
+    _call("ovd_quant_heads_i8", _ptr(x, BF16), x.stride(1), x.stride(0), _ptr(q, torch.int8), q.stride(1), q.stride(0),
+          _ptr(scale, F32), B, L, N, D, int(rows_per_scale), _stream())
+
+
+def flash_attn_qk8(q8, q_scale, k8, k_scale, v, out, k_len=None, softmax_scale=None, workspace=None):
+    """Self-attention with Q K^T on int8 operands (quant_heads_i8 with rows_per_scale 1 for q, 64 for k)."""
+    B, Lq, N, D = q8.shape
+    Lk = k8.shape[1]
+    for t in (q8, k8, v, out):
+        if t.dim() != 4 or t.stride(3) != 1 or t.stride(2) != D:
+            raise ValueError("attention: tensors must be [B,L,N,D] with dense (N,D)")
+    if k8.shape != v.shape or out.shape != q8.shape or k8.shape[0] != B or k8.shape[2] != N:
+        raise ValueError("attention: shape mismatch")
+    if tuple(q_scale.shape) != (B, Lq, N) or tuple(k_scale.shape) != (B, -(-Lk // 64), N) \
+            or not q_scale.is_contiguous() or not k_scale.is_contiguous():
+        raise ValueError("attention: scales must be contiguous [B, Lq, N] and [B, ceil(Lk/64), N]")
+    scale = float(softmax_scale) if softmax_scale is not None else D ** -0.5
+    ws_ptr, ws_bytes = (None, 0) if workspace is None else (workspace.data_ptr(), workspace.numel() * workspace.element_size())
+    _call("ovd_flash_attn_qk8_fwd_bf16", _ptr(q8, torch.int8), _ptr(q_scale, F32), _ptr(k8, torch.int8), _ptr(k_scale, F32),
+          _ptr(v, BF16), _ptr(out, BF16), B, Lq, Lk, N, D, int(Lk if k_len is None else k_len), q8.stride(1), k8.stride(1),
+          v.stride(1), out.stride(1), q8.stride(0), k8.stride(0), v.stride(0), out.stride(0), scale, ws_ptr, ws_bytes,
+          _stream())
     return out
 
 

@@ -129,15 +129,22 @@ FP8_LINEARS = ("qkv", "o", "cq", "co", "f0", "f2")
 
 
 class DiTEngine:
-    def __init__(self, model, device=None, precision="bf16"):
+    def __init__(self, model, device=None, precision="bf16", attention=None):
         """model: omnivideo.modules.model.WanModel (parameters are read, never modified).
         precision: "bf16" (the reference's arithmetic) or "fp8": the six large linear layers of
         every block run on e4m3 operands - weights quantised once with a scale per output
         channel, activations per token row inside the kernel that produces them (the GELU output
-        with the fixed scale `ffn_act_scale`); everything else is unchanged."""
+        with the fixed scale `ffn_act_scale`).
+        attention: "bf16", or "int8": self-attention computes Q K^T on int8 operands (q with a scale per
+        token and head, k per 64-key tile and head; softmax, P and P V unchanged); default: "int8"
+        with precision "fp8", else "bf16".  Cross-attention, norms, the residual stream and the head
+        are the same in every mode."""
         if precision not in ("bf16", "fp8"):
             raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
-        self.precision = precision
+        attention = attention or ("int8" if precision == "fp8" else "bf16")
+        if attention not in ("bf16", "int8"):
+            raise ValueError(f"attention must be 'bf16' or 'int8', got {attention!r}")
+        self.precision, self.attention = precision, attention
         self.ffn_act_scale = 1.0
         p0 = model.patch_embedding.weight
         self.device = torch.device(device) if device is not None else p0.device
@@ -233,6 +240,10 @@ class DiTEngine:
         # self-attention runs over the full sequence for N / sp heads: workspace for its tail balancing
         ws = H.flash_attn_workspace_bytes(nb, seq_len, N // sp, n_tok)
         self.attn_ws = torch.empty(ws, dtype=torch.uint8, device=dev) if ws > 0 else None
+        if self.attention == "int8":         # self-attention operands: full sequence, this rank's heads
+            self.q8, self.k8 = e(nb, seq_len, C // sp, dt=torch.int8), e(nb, seq_len, C // sp, dt=torch.int8)
+            self.q8_scale = e(nb, seq_len, N // sp, dt=F32)
+            self.k8_scale = e(nb, -(-seq_len // 64), N // sp, dt=F32)
         if sp > 1:
             Cs = C // sp
             self.sp_send = e(3, nb, sp, S, Cs)        # q|k|v of my rows, split by destination head group
@@ -269,10 +280,18 @@ class DiTEngine:
 
     # ------------------------------------------------------------------ attention variants
     def _self_attention(self, q4, k4, v4, att4):
+        int8 = self.attention == "int8"
+        if int8:
+            q8, k8 = (t.unflatten(2, (q4.shape[2], q4.shape[3])) for t in (self.q8, self.k8))
+            H.quant_heads_i8(q4, q8, self.q8_scale, 1)
+            H.quant_heads_i8(k4, k8, self.k8_scale, 64)
         if self.timing is not None:      # profiling hook: events around the dominant kernel
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        H.flash_attn(q4, k4, v4, att4, k_len=self.n_tok, workspace=self.attn_ws)
+        if int8:
+            H.flash_attn_qk8(q8, self.q8_scale, k8, self.k8_scale, v4, att4, k_len=self.n_tok, workspace=self.attn_ws)
+        else:
+            H.flash_attn(q4, k4, v4, att4, k_len=self.n_tok, workspace=self.attn_ws)
         if self.timing is not None:
             ev[1].record()
             self.timing.append(ev)

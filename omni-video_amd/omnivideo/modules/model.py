@@ -292,16 +292,19 @@ class WanModel(nn.Module):
         # "bf16" = the reference's arithmetic; "fp8" = e4m3 operands for the six large linear layers of
         # every block (an extension: the reference has no such mode).  Takes effect at the next forward.
         self.linear_precision = "bf16"
+        # self-attention operands: "auto" = int8 Q K^T in the fp8 mode, bf16 otherwise; "bf16" / "int8" force one
+        self.attention_precision = "auto"
 
     # ---- engine management --------------------------------------------------------
     def _weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def engine(self):
-        key = (self._weights_key(), self.linear_precision)
+        key = (self._weights_key(), self.linear_precision, self.attention_precision)
         if self._engine is None or self._engine_key != key:
             self._engine = None                      # release the old copies before building new ones
-            self._engine = DiTEngine(self, precision=self.linear_precision)
+            self._engine = DiTEngine(self, precision=self.linear_precision,
+                                     attention=None if self.attention_precision == "auto" else self.attention_precision)
             self._engine_key = key
             self._ctx_key = None
         return self._engine

@@ -6,6 +6,8 @@ import math
 import pytest
 import torch
 
+from conftest import check_rel
+
 pytestmark = pytest.mark.gpu
 BF16, F32, F8 = torch.bfloat16, torch.float32, torch.float8_e4m3fn
 
@@ -169,7 +171,7 @@ def rel_l2(a, b):
 
 def test_model_forward_fp8_vs_bf16_path():
     """The tolerance of the FP8 mode is defined against this build's own bf16 path (itself checked
-    against the oracle and the reference's goldens): relative L2 of one forward below 6e-2."""
+    against the oracle and the reference's goldens): relative L2 of one forward; the mode's budget is 6e-2, the asserts sit at three times what was observed."""
     from omnivideo.utils import synthetic as syn
     cfg, m = _tiny_unified()
     wm = m.wan_model
@@ -181,8 +183,14 @@ def test_model_forward_fp8_vs_bf16_path():
     got = wm([lat], t, ctx, 72)[0].clone()
     assert wm.engine().precision == "fp8" and wm.engine().layers[0]["w_qkv"] is None
     assert torch.isfinite(got).all()
+    assert wm.engine().attention == "int8"
     r = rel_l2(got, ref)
-    assert 1e-4 < r < 6e-2, r                 # different arithmetic, same function
+    check_rel("tiny forward, fp8 linears + int8 QK^T vs bf16 path", r, 1e-2)              # observed 3.4e-3
+    assert r > 1e-4                           # different arithmetic, same function
+    wm.attention_precision = "bf16"           # e4m3 linear layers alone
+    r_lin = rel_l2(wm([lat], t, ctx, 72)[0], ref)
+    check_rel("tiny forward, fp8 linears (bf16 attention) vs bf16 path", r_lin, 1e-2)     # observed 3.4e-3
+    wm.attention_precision = "auto"
     assert torch.equal(wm([lat], t, ctx, 72)[0], got)          # deterministic
     wm.linear_precision = "bf16"
     assert torch.equal(wm([lat], t, ctx, 72)[0], ref)          # and switching back restores the bf16 path
@@ -217,7 +225,8 @@ def test_full_width_block_fp8_vs_bf16_full_grid():
         outs[prec] = out
         del eng
     r = rel_l2(outs["fp8"], outs["bf16"])
-    assert torch.isfinite(outs["fp8"]).all() and r < 6e-2, r
+    assert torch.isfinite(outs["fp8"]).all()
+    check_rel("2 blocks of 1.3B width, full grid, fp8 linears + int8 QK^T vs bf16 path", r, 6e-3)   # observed 1.7e-3
 
 
 def test_generate_fp8_linear_mode_tracks_bf16_trajectory():
@@ -247,4 +256,5 @@ def test_generate_fp8_linear_mode_tracks_bf16_trajectory():
                                    size=(96, 64), frame_num=9, shift=5.0, sampling_steps=8, guide_scale=3.0, seed=1,
                                    noise=noise, return_latents=True).float()
     r = rel_l2(lats["fp8"], lats["bf16"])
-    assert torch.isfinite(lats["fp8"]).all() and 1e-4 < r < 8e-2, r
+    assert torch.isfinite(lats["fp8"]).all() and r > 1e-4
+    check_rel("8-step generate(), fp8 linears + int8 QK^T vs bf16 run", r, 1.5e-2)   # observed 4.8e-3

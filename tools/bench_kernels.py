@@ -64,6 +64,28 @@ def attn(B, Lq, Lk, N, k_len=None, check=False, strided_q=False, fused_kv=False,
     print(msg, flush=True)
 
 
+def attn_qk8(B, L, N):
+    """self-attention with int8 Q K^T beside the bf16 kernel on the same inputs (both with tail balancing)"""
+    D = 128
+    q, k, v = (torch.randn(B, L, N, D, device="cuda").to(BF16) for _ in range(3))
+    q8, k8 = (torch.empty(B, L, N, D, device="cuda", dtype=torch.int8) for _ in range(2))
+    qs = torch.empty(B, L, N, device="cuda")
+    ks = torch.empty(B, -(-L // 64), N, device="cuda")
+    o = torch.empty_like(q)
+    nbytes = H.flash_attn_workspace_bytes(B, L, N, L)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if nbytes else None
+    fl = 4.0 * B * N * L * L * D
+    ms = timeit(lambda: H.flash_attn(q, k, v, o, workspace=ws))
+    def quant():
+        H.quant_heads_i8(q, q8, qs, 1)
+        H.quant_heads_i8(k, k8, ks, 64)
+    msq = timeit(quant)
+    quant()
+    ms8 = timeit(lambda: H.flash_attn_qk8(q8, qs, k8, ks, v, o, workspace=ws))
+    print(f"attn B{B} L{L} N{N}: bf16 {ms:.3f} ms {fl / ms / 1e9:.0f} TFLOP/s | int8 QK^T {ms8:.3f} ms "
+          f"{fl / ms8 / 1e9:.0f} TFLOP/s (+ quantise q,k {msq * 1e3:.0f} us) | ratio {ms / (ms8 + msq):.3f}", flush=True)
+
+
 def gemm(M, N, K, epi=0, check=False, uniform=False):
     if uniform:     # operands uniform in [-1, 1): the distribution published GEMM numbers are quoted on
         a = (torch.rand(M, K, device="cuda") * 2 - 1).to(BF16)
@@ -147,6 +169,9 @@ if __name__ == "__main__":
         attn(2, 20280, 20280, 12)
         attn(2, 20280, 20280, 12, balance=True)
         attn(2, 20280, 6144, 12)
+    if "attn8" in args.what:
+        attn_qk8(2, 20280, 12)
+        attn_qk8(2, 75600, 5)
     if "attnbal" in args.what:      # the cfg2 self-attention launch alone (for counter passes)
         attn(2, 20280, 20280, 12, balance=True)
     if "xattn131" in args.what:     # cross-attention as the cfg2 model runs it: 131 keys read, fused K|V cache
