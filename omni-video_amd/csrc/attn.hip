@@ -31,6 +31,13 @@
 // stores 16 bytes and a store instruction covers whole 256-byte head rows instead of
 // 8-byte pieces in accumulator order.
 //
+// Reduced-precision form (template parameter I8; the reference has none): Q K^T on int8 operands with
+// v_mfma_i32_32x32x32_i8 - half the matrix time of the bf16 product; q carries a scale per token and
+// head, k a scale per 64-key tile and head (ovd_impl_quant_heads_i8), both folded into the exp2
+// multiplier, so the vector work per score is unchanged.  K tiles are 64 rows of 128 bytes.  The int32
+// accumulators start at the bit pattern of 1.5 * 2^23, which makes the finished accumulator the float
+// 12582912 + score: no conversion instruction per score.  Softmax, P (bf16) and P V are shared.
+//
 // Tail balancing: all workgroups of a launch take the same time, so a grid that is not a
 // multiple of the CU count ends in a partly filled round.  When attn_split_plan() finds
 // such a tail, the trailing query blocks of every XCD are split over the two halves of the
@@ -208,8 +215,8 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
     }
     // K fragments are fetched one k-step ahead; the scheduling fences keep each k-step's
     // {2 LDS reads, 2 MFMAs, its share of the softmax} together so that register life times
-    // stay short and the vector work sits in the MFMA shadows.  24 of the 32 scores are
-    // finished here (4 / 2 per k-step), the last 8 beside the first P V products.
+    // stay short and the vector work sits in the MFMA shadows.  16 of the 32 scores are
+    // finished here, the other 16 beside the first three P V steps.
     if constexpr (!I8) {
         bf16x8 kf[2][2];
         if (HAS_NEXT) {
@@ -226,9 +233,7 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
                 n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][0], qf[ks], n0, 0, 0, 0);
                 n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][1], qf[ks], n1, 0, 0, 0);
             }
-            const int pi = 3 * (ks >> 1) + 2 * (ks & 1);      // first pair of this k-step: 0,2,3,5,6,8,9,11
-            SOFTMAX_PAIR(pi);
-            if (!(ks & 1)) SOFTMAX_PAIR(pi + 1);
+            SOFTMAX_PAIR(ks);           // one pair per k-step (12 of 16 pairs here ran 1.3 % slower than 8)
             if (ks == 0) stage_next<NW>(ks_, k_dst);
             if (ks == 1) stage_next<NW>(vs_, v_dst);
             if (ks == 7) READ_V(0, vf[0]);
@@ -276,14 +281,10 @@ __device__ __forceinline__ void pipe_step(f32x16 (&o_acc)[4], const bf16x8 (&qf)
 #pragma unroll
         for (int db = 0; db < 4; ++db)
             o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st & 1][db], pfrag, o_acc[db], 0, 0, 0);
-        if (I8) {                 // pairs 8-10, 11-13, 14-15 (each four are packed before the step that multiplies them)
-            if (st == 0) { SOFTMAX_PAIR(8); SOFTMAX_PAIR(9); SOFTMAX_PAIR(10); }
-            if (st == 1) { SOFTMAX_PAIR(11); SOFTMAX_PAIR(12); SOFTMAX_PAIR(13); }
-            if (st == 2) { SOFTMAX_PAIR(14); SOFTMAX_PAIR(15); }
-        } else if (st < 2) {
-            SOFTMAX_PAIR(12 + 2 * st);
-            SOFTMAX_PAIR(13 + 2 * st);
-        }
+        // pairs 8-10, 11-13, 14-15 (each four are packed before the step that multiplies them)
+        if (st == 0) { SOFTMAX_PAIR(8); SOFTMAX_PAIR(9); SOFTMAX_PAIR(10); }
+        if (st == 1) { SOFTMAX_PAIR(11); SOFTMAX_PAIR(12); SOFTMAX_PAIR(13); }
+        if (st == 2) { SOFTMAX_PAIR(14); SOFTMAX_PAIR(15); }
         if (st >= 2 && HAS_NEXT) {
             const f32x16& n = st == 2 ? n0 : n1;
 #pragma unroll
