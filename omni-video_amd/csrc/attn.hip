@@ -345,8 +345,13 @@ attn_fwd_pipe(const void* __restrict__ Qv, const void* __restrict__ Kv, const bf
             pair = (id & 7) + 8 * (j / n_qblocks);
             qb = j % n_qblocks;
         } else {
-            pair = id / n_qblocks;
-            qb = id % n_qblocks;
+            // any other pair count: XCD x (= id % 8) gets one contiguous range of the (pair, query block)
+            // space, so its CUs stream the same K/V at the same time (consecutive ids would put all 8 XCDs
+            // on one pair, each fetching that pair's K/V for itself: 8.5x the algorithmic bytes at 10 pairs)
+            const int total = pairs * n_qblocks, xcd = id & 7, q = total >> 3, r = total & 7;
+            const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+            pair = lin / n_qblocks;
+            qb = lin % n_qblocks;
         }
     }
     const int head = pair % n_heads, b = pair / n_heads;
