@@ -17,37 +17,39 @@ def init_distributed_group():
         dist.init_process_group(backend="nccl")
 
 
+def _join_partition(blocks):
+    """Creates one process group per block of `blocks` (a partition of the world's ranks; every rank
+    has to take part in every `new_group` call, in the same order) and returns the group this rank
+    belongs to."""
+    me, mine = dist.get_rank(), None
+    for ranks in blocks:
+        group = dist.new_group(list(ranks))
+        if me in ranks:
+            mine = group
+    return mine
+
+
 def init_sequence_parallel_group(sp_size):
-    """Contiguous rank blocks of size sp_size (reference util.py:16-40)."""
+    """Sequence-parallel groups = consecutive blocks of sp_size ranks (reference util.py:16-40); the
+    group of this rank is remembered for the getters below."""
+    global _SEQUENCE_PARALLEL_GROUP, _SEQUENCE_PARALLEL_SIZE
     if not dist.is_initialized():
         return None
-    world_size = dist.get_world_size()
-    assert world_size % sp_size == 0
-    rank = dist.get_rank()
-    sp_group = None
-    for i in range(world_size // sp_size):
-        ranks = list(range(i * sp_size, (i + 1) * sp_size))
-        group = dist.new_group(ranks)
-        if rank in ranks:
-            sp_group = group
-    global _SEQUENCE_PARALLEL_GROUP, _SEQUENCE_PARALLEL_SIZE
-    _SEQUENCE_PARALLEL_GROUP = sp_group
+    world = dist.get_world_size()
+    if world % sp_size:
+        raise AssertionError(f"world size {world} is not a multiple of sp_size {sp_size}")
+    _SEQUENCE_PARALLEL_GROUP = _join_partition(range(b * sp_size, (b + 1) * sp_size) for b in range(world // sp_size))
     _SEQUENCE_PARALLEL_SIZE = sp_size
-    return sp_group
+    return _SEQUENCE_PARALLEL_GROUP
 
 
 def init_distributed_groups(sp_size):
-    """Orthogonal data-parallel and sequence-parallel groups (reference util.py:43-66)."""
-    if not dist.is_initialized():
-        dist.init_process_group(backend="nccl")
-    world_size, rank = dist.get_world_size(), dist.get_rank()
+    """(data-parallel group, sequence-parallel group) of this rank: the data-parallel groups are the
+    strided complements of the sequence-parallel blocks (reference util.py:43-66)."""
+    init_distributed_group()
+    world = dist.get_world_size()
     sp_group = init_sequence_parallel_group(sp_size)
-    dp_group = None
-    for i in range(sp_size):
-        ranks = [i + j * sp_size for j in range(world_size // sp_size)]
-        group = dist.new_group(ranks)
-        if rank in ranks:
-            dp_group = group
+    dp_group = _join_partition(range(offset, world, sp_size) for offset in range(sp_size))
     return dp_group, sp_group
 
 

@@ -20,8 +20,10 @@ def main():
     dist.init_process_group("gloo", init_method="env://")
     world, rank = dist.get_world_size(), dist.get_rank()
     sp = int(os.environ.get("SP_SIZE", world))
-    group = U.init_sequence_parallel_group(sp)
+    dp_group, group = U.init_distributed_groups(sp)
     assert U.get_sequence_parallel_size() == sp and U.get_world_size(group) == sp
+    # data-parallel groups are the strided complements: ranks {r % sp == const}
+    assert dist.get_world_size(dp_group) == world // sp and dist.get_rank(dp_group) == rank // sp
     r = U.get_rank(group)
     assert r == rank % sp
 
