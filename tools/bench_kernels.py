@@ -309,6 +309,21 @@ if __name__ == "__main__":
             H.gemm(ffn, w2, res, b2, H.EPI_BF16)
         ms = timeit(pair)
         print(f"FFN-up + FFN-down M{M}: {ms:.3f} ms  {4.0 * M * C * F / ms / 1e9:.0f} TFLOP/s")
+    if "ffnchunk" in args.what:     # the same pair in row chunks: the intermediate of a chunk is consumed while still cache-resident
+        M, C, F = 40560, 1536, 8960
+        hb = torch.randn(M, C, device="cuda").to(BF16)
+        ffn = torch.empty(M, F, device="cuda", dtype=BF16)
+        res = torch.empty(M, C, device="cuda", dtype=BF16)
+        w0 = (torch.randn(F, C, device="cuda") / 40).to(BF16)
+        w2 = (torch.randn(C, F, device="cuda") / 90).to(BF16)
+        b0, b2 = torch.zeros(F, device="cuda", dtype=BF16), torch.zeros(C, device="cuda", dtype=BF16)
+        for rows in (M, 20480, 10240, 8192, 5120):
+            def run():
+                for r0 in range(0, M, rows):
+                    H.gemm(hb[r0:r0 + rows], w0, ffn[r0:r0 + rows], b0, H.EPI_BF16_GELU)
+                    H.gemm(ffn[r0:r0 + rows], w2, res[r0:r0 + rows], b2, H.EPI_BF16)
+            ms = timeit(run)
+            print(f"FFN-up + FFN-down M{M} in chunks of {rows} rows: {ms:.3f} ms  {4.0 * M * C * F / ms / 1e9:.0f} TFLOP/s", flush=True)
     if "gemmdown" in args.what:     # one shape for counter passes: FFN-down of the batched step
         gemm(40960, 1536, 8960, 0)
     if "gemmlib" in args.what:      # the vendor library (torch -> hipBLASLt) on the step's GEMM shapes, for orientation
