@@ -10,6 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def launch(nproc, sp, port):
+    import socket
+    with socket.socket() as sk:          # any free port (the parameter only labels the case)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, SP_SIZE=str(sp), OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "_sp_worker.py")]

@@ -19,7 +19,15 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def launch(script, args, nproc, port, timeout=300):
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch(script, args, nproc, timeout=300):
+    port = free_port()
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, script)] + list(args)
@@ -29,7 +37,7 @@ def launch(script, args, nproc, port, timeout=300):
 
 
 def test_generate_with_usp_two_processes_equals_single_process(tmp_path):
-    launch("_sp_gpu_worker.py", ["generate", str(tmp_path)], 2, 29641)
+    launch("_sp_gpu_worker.py", ["generate", str(tmp_path)], 2)
     with torch.no_grad():
         pipe, cfg = case.build_pipeline(use_usp=False)
         lat, video = case.run_generate(pipe, cfg)
@@ -46,7 +54,7 @@ def test_generate_with_usp_two_processes_equals_single_process(tmp_path):
 
 
 def test_sp_attention_forwards_two_processes_equal_unsharded(tmp_path):
-    launch("_sp_gpu_worker.py", ["attention", str(tmp_path)], 2, 29642)
+    launch("_sp_gpu_worker.py", ["attention", str(tmp_path)], 2)
     with torch.no_grad():
         pipe, cfg = case.build_pipeline(use_usp=False)
         blk = pipe.high_noise_model.wan_model.blocks[1]
@@ -62,4 +70,4 @@ def test_sp_attention_forwards_two_processes_equal_unsharded(tmp_path):
 
 
 def test_rccl_communicator_single_rank_group(tmp_path):
-    launch("_nccl_worker.py", [str(tmp_path)], 1, 29643)
+    launch("_nccl_worker.py", [str(tmp_path)], 1)
