@@ -24,9 +24,19 @@ def rope(x, L):
     return torch.stack([a * c - b * s, a * s + b * c], -1).flatten(-2).float()
 
 
-def attend(q, k, v):
+def attend(q, k, v, p8=False):
+    """p8: the probabilities (relative to the row maximum, as a flash kernel holds them) rounded to e4m3
+    before P V instead of to bf16; the row sum stays in fp32."""
     s = torch.einsum("qnd,knd->nqk", q, k) / math.sqrt(q.shape[-1])
-    return torch.einsum("nqk,knd->qnd", torch.softmax(s, -1).to(torch.bfloat16).float(), v)
+    if not p8:
+        return torch.einsum("nqk,knd->qnd", torch.softmax(s, -1).to(torch.bfloat16).float(), v)
+    e = torch.exp(s - s.amax(-1, keepdim=True))
+    return torch.einsum("nqk,knd->qnd", e.to(F8).float(), v) / e.sum(-1).t()[:, :, None]
+
+
+def q_chan(v):               # e4m3 with one scale per (head, channel) over the whole sequence
+    s = v.abs().amax(0, keepdim=True).clamp_min(1e-12) / 448.0
+    return (v / s).to(F8).float() * s
 
 
 def q_tok(x, kind):          # one scale per (token, head)
@@ -66,7 +76,9 @@ def main(L=4096, C=1536, N=12, sharp=1.0, outlier=0.0):
             ("e4m3 Q,K per token", rel(attend(q_tok(q, "e4m3"), q_tok(k, "e4m3"), v))),
             ("int8 Q per token, K per token", rel(attend(q_tok(q, "i8"), q_tok(k, "i8"), v))),
             ("int8 Q per token, K per 64-key tile", rel(attend(q_tok(q, "i8"), q_tile(k), v))),
-            ("int8, K mean removed, per 64-key tile", rel(attend(q_tok(q, "i8"), q_tile(km), v)))]
+            ("int8, K mean removed, per 64-key tile", rel(attend(q_tok(q, "i8"), q_tile(km), v))),
+            ("int8 Q K^T + e4m3 P, bf16 V", rel(attend(q_tok(q, "i8"), q_tile(k), v, p8=True))),
+            ("int8 Q K^T + e4m3 P and V (per channel)", rel(attend(q_tok(q, "i8"), q_tile(k), q_chan(v), p8=True)))]
     print(f"L={L} C={C} heads={N} logit scale x{sharp} key-channel offsets x{outlier}")
     for name, e in rows:
         print(f"  {name:42s} rel L2 {e:.2e}")
