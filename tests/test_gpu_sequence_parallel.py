@@ -55,9 +55,11 @@ def build(cfg, sd):
     return m.to(BF16).cuda().eval().wan_model
 
 
-@pytest.mark.parametrize("heads,sp,seq_len", [(2, 2, 72), (2, 2, 80), (4, 4, 80), (4, 2, 76)])
-def test_sharded_forward_equals_unsharded(heads, sp, seq_len):
-    from omnivideo.modules.engine import DiTEngine
+@pytest.mark.parametrize("heads,sp,seq_len,precision", [(2, 2, 72, "bf16"), (2, 2, 80, "bf16"), (4, 4, 80, "bf16"),
+                                                        (4, 2, 76, "bf16"), (4, 2, 80, "fp8"), (2, 2, 72, "fp8")])
+def test_sharded_forward_equals_unsharded(heads, sp, seq_len, precision):
+    from omnivideo.modules.engine import DiTEngine as _Engine
+    DiTEngine = lambda wm: _Engine(wm, precision=precision)     # fp8: e4m3 linear layers + int8 Q K^T
     cfg = syn.dit_config("tiny", dim=128 * heads, num_heads=heads, ffn_dim=512)
     sd = syn.make_unified_state_dict(cfg, 0)
     wm = build(cfg, sd)
