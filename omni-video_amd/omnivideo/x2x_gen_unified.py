@@ -147,7 +147,9 @@ class DenoiseLoop:
                 g = _SegmentedGraph(lambda: self._step(key), self.engines[key])
             else:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: other threads of the process (e.g. a process group's watchdog polling its
+                # events) must not be able to invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._step(key)
             self.graphs[key] = g
 
