@@ -18,57 +18,65 @@ except ImportError:          # pragma: no cover - depends on the installation
 _warned = False
 
 
+_PUNCT = str.maketrans("", "", string.punctuation)
+_SPACES = re.compile(r"\s+")
+
+
 def basic_clean(text):
+    """Mojibake repair (when ftfy is present), two rounds of HTML unescaping, outer whitespace off
+    (reference tokenizers.py:12-15)."""
     global _warned
     if ftfy is not None:
         text = ftfy.fix_text(text)
     elif not _warned:
         logging.warning("ftfy is not installed: prompts are not mojibake-repaired before tokenization")
         _warned = True
-    text = html.unescape(html.unescape(text))
-    return text.strip()
+    return html.unescape(html.unescape(text)).strip()
 
 
 def whitespace_clean(text):
-    return re.sub(r"\s+", " ", text).strip()
+    """Runs of whitespace become one space (reference tokenizers.py:18-21)."""
+    return _SPACES.sub(" ", text).strip()
 
 
 def canonicalize(text, keep_punctuation_exact_string=None):
+    """Underscores to spaces, punctuation dropped (except the given literal), lower case, single
+    spaces (reference tokenizers.py:24-35)."""
     text = text.replace("_", " ")
-    table = str.maketrans("", "", string.punctuation)
-    if keep_punctuation_exact_string:
-        text = keep_punctuation_exact_string.join(part.translate(table)
-                                                  for part in text.split(keep_punctuation_exact_string))
-    else:
-        text = text.translate(table)
-    return re.sub(r"\s+", " ", text.lower()).strip()
+    pieces = text.split(keep_punctuation_exact_string) if keep_punctuation_exact_string else [text]
+    text = (keep_punctuation_exact_string or "").join(p.translate(_PUNCT) for p in pieces)
+    return _SPACES.sub(" ", text.lower()).strip()
+
+
+_CLEANERS = {
+    None: None,
+    "whitespace": lambda t: whitespace_clean(basic_clean(t)),
+    "lower": lambda t: whitespace_clean(basic_clean(t)).lower(),
+    "canonicalize": lambda t: canonicalize(basic_clean(t)),
+}
 
 
 class HuggingfaceTokenizer:
+    """`tokenizer(texts, return_mask=False, **hf_kwargs)` -> ids (and mask), padded and truncated to
+    `seq_len` when one is given (reference tokenizers.py:38-81). Files come from the local directory
+    `name` only."""
 
     def __init__(self, name, seq_len=None, clean=None, **kwargs):
-        assert clean in (None, "whitespace", "lower", "canonicalize")
+        if clean not in _CLEANERS:
+            raise AssertionError(f"clean must be one of {sorted(k for k in _CLEANERS if k)} or None")
         from transformers import AutoTokenizer
         self.name, self.seq_len, self.clean = name, seq_len, clean
+        self._clean = _CLEANERS[clean]
         self.tokenizer = AutoTokenizer.from_pretrained(name, local_files_only=True, **kwargs)
         self.vocab_size = self.tokenizer.vocab_size
 
-    def __call__(self, sequence, **kwargs):
-        return_mask = kwargs.pop("return_mask", False)
-        _kwargs = {"return_tensors": "pt"}
+    def __call__(self, sequence, return_mask=False, **kwargs):
+        texts = [sequence] if isinstance(sequence, str) else list(sequence)
+        if self._clean is not None:
+            texts = [self._clean(t) for t in texts]
+        options = {"return_tensors": "pt"}
         if self.seq_len is not None:
-            _kwargs.update({"padding": "max_length", "truncation": True, "max_length": self.seq_len})
-        _kwargs.update(**kwargs)
-        if isinstance(sequence, str):
-            sequence = [sequence]
-        if self.clean:
-            sequence = [self._clean(u) for u in sequence]
-        ids = self.tokenizer(sequence, **_kwargs)
-        return (ids.input_ids, ids.attention_mask) if return_mask else ids.input_ids
-
-    def _clean(self, text):
-        if self.clean == "whitespace":
-            return whitespace_clean(basic_clean(text))
-        if self.clean == "lower":
-            return whitespace_clean(basic_clean(text)).lower()
-        return canonicalize(basic_clean(text))
+            options.update(padding="max_length", truncation=True, max_length=self.seq_len)
+        options.update(kwargs)
+        enc = self.tokenizer(texts, **options)
+        return (enc.input_ids, enc.attention_mask) if return_mask else enc.input_ids
