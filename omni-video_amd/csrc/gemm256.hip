@@ -1,44 +1,52 @@
 // Large-shape bf16 GEMM with the epilogues of gemm.hip:
 //   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] + bias[n] ),  A [M,K], W [N,K] (nn.Linear).
 //
-// One workgroup = 8 waves = a 256 x 256 output tile; wave (wr, wc) = (w >> 2, w & 3) owns
-// 128 rows x 64 columns = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 (128 accumulator
-// registers), computed transposed (weight rows on the MFMA M axis) so that a lane ends up
-// with 4 consecutive output columns of one row.
+// One workgroup = 8 waves = a 256 x 256 output tile, one workgroup per CU.  Wave (wr, wc) = (w >> 2, w & 3)
+// owns rows {wr*64 .. +63} of BOTH 128-row halves of the A tile and weight rows {wc*32 .. +31} of both
+// halves of the W tile: 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 (128 accumulator registers), computed
+// transposed (weight rows on the MFMA M axis) so that a lane ends up with 4 consecutive output columns
+// of one row.
 //
-// Operands stream HBM -> LDS with 16-byte global_load_lds; K-tiles of 32 are staged in PAIRS
-// (K % 64 == 0).  LDS rows are 128 B (64 k-values), so every DMA instruction
-// fetches 8 whole 128-byte lines; the ring holds 2 pairs of 64 KiB (A part 256 rows x 128 B |
-// W part 256 rows x 128 B; one workgroup per CU).  16-byte chunk c of row r sits at chunk position
-// c ^ ((r >> 1) & 7): every 16-lane group of a ds_read_b128 fragment read (either half of the row)
-// hits 16 distinct bank slots.  The swizzle is applied on the SOURCE address of the DMA (its LDS
-// image is lane-linear) and again on the read address.  The even K-tile of a pair puts the whole
-// next pair in flight (8 DMA instructions per wave) into the other slot, the odd one waits for it.
-// (A ring of 4 single K-tiles with 64-byte rows, half a line per row and DMA instruction, ran 1-4 %
-// slower.)
+// Operands stream HBM -> LDS with 16-byte global_load_lds in K-tiles of 64.  LDS rows are 128 B (64
+// k-values), so every DMA instruction fetches 8 whole 128-byte lines; two buffers of 64 KiB
+// (A part 256 rows x 128 B | W part 256 rows x 128 B).  16-byte chunk c of row r sits at chunk position
+// c ^ ((r >> 1) & 7): every 16-lane group of a ds_read_b128 fragment read (either half of the row) hits 16
+// distinct bank slots.  The swizzle is applied on the SOURCE address of the DMA (its LDS image is
+// lane-linear) and again on the read address.
 //
-// A K-tile is one phase per wave: 12 fragment reads, then 32 MFMAs.  The two waves that share a
-// SIMD (w and w + 4) run half a period apart: waves 4-7 execute one extra s_barrier before the loop
-// (waves 0-3 one after it), so that one of them issues its LDS reads and DMA while the other one
-// feeds the matrix pipe.
-//
-// What bounds the loop (measured): the operand stream into the CU.  At 128 FLOP per staged byte the
-// kernel moves ~18 B/clk/CU at 1.25 PFLOP/s; removing half of the DMA (wrong results, timing only)
-// ran at 1.59 PFLOP/s, while a deeper ring (5 tiles), DMA issued from inside the MFMA phase, and one
-// operand staged through registers + ds_write_b128 all ran within 2 % of the plain loop.
+// A K-tile is four phases of 16 MFMAs.  Every phase puts ONE 16 KiB half-tile (128 rows of one operand)
+// in flight, 2 DMA instructions per wave, and the DMA queue is never drained inside the loop:
+//   phase 1: read W-half0 (4 fragments) and A-half0 (8), MFMA quadrant (A0, W0); stage W-half1 of K-tile t+1
+//   phase 2: read W-half1 (4),                           MFMA (A0, W1);            stage A-half1 of t+1
+//   phase 3: read A-half1 (8),                           MFMA (A1, W1);            stage W-half0 of t+2
+//   phase 4: -,                                          MFMA (A1, W0);            stage A-half0 of t+2
+// Because every wave reads a given half-tile in the same phase, the half-tile is free for the K-tile after
+// next right behind that phase.  The two waves that share a SIMD (w and w + 4) run one barrier apart:
+// waves 4-7 execute one extra s_barrier before the loop (waves 0-3 one after it), so one of them issues its
+// LDS reads and DMA while the other one feeds the matrix pipe.
 //
 // Hazards the schedule is built around:
-//   * a wave's fragment reads are complete (lgkmcnt(0)) BEFORE the barrier that ends its read
-//     phase, so the slot of the previous pair can be re-staged right behind that barrier;
-//   * raw s_barrier + explicit waits only inside the loop: a __syncthreads() would drain the DMA queue;
+//   * write-after-read: a half-tile is restaged two or more phases after its last read (the reads are
+//     retired by the lgkmcnt(0) behind the phase's first barrier, for the later wave group one barrier on);
+//   * read-after-write: a half-tile is read one phase after the counted wait that retires it
+//     (vmcnt(8) = every DMA issued four or more phases ago has landed) and the barrier behind that wait;
+//   * raw s_barrier + counted waits only inside the loop: a __syncthreads() would drain the DMA queue;
 //   * no ordinary global load while DMA is in flight (bias / gate are read in the epilogue).
+//
+// Measured on the loop (FFN-down shape, K = 8960): matrix pipe busy in 73 % of the kernel's cycles.
+// Without any DMA in the loop (timing only) it runs 19 % faster, with every tile streaming the same
+// L2-resident operands 9 % faster; waiting for DMA issued two phases ago instead of four costs 1 %
+// (latency is covered; what remains is the L2 -> LDS path's throughput).  Raising the waves' priority
+// for the MFMA phase costs 1-3 %, handing the matrix pipe over 2-8 MFMAs before the end of a phase
+// 4-7 %, retiring the fragment reads before the barrier instead of behind it 1-2 %.
 #include "common.h"
 
 namespace {
 
-constexpr int TM = 256, TN = 256, TK = 32;
-constexpr int PAIR = 2 * 2 * 256 * TK * 2;   // two K-tiles staged together: A part 32 KiB | W part 32 KiB
-constexpr int NPAIR = 2;                     // pairs in the ring
+constexpr int TM = 256, TN = 256;
+constexpr int KT = 64;                        // K-tile
+constexpr int PAIR = 2 * 256 * KT * 2;        // one buffer: A part 32 KiB | W part 32 KiB
+constexpr int NPAIR = 2;                      // buffers
 
 enum Epi { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3 };
 
@@ -51,53 +59,109 @@ struct Src4 {
     unsigned off[4];       // this lane's byte offsets (clamped row * ld + swizzled chunk) for its four rows
 };
 
-__device__ __forceinline__ void stage_part4(const Src4& s, long kbyte, char* dst_wave) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[i], (lds_ptr)(dst_wave + i * 8192), 16, 0, 0);
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-// One K-tile (half of the pair in `slot`; lane_off selects the half).  STAGE_NEXT: put the next pair in
-// flight into the other slot; WAIT: retire this wave's share of it.
-template <bool STAGE_NEXT, bool WAIT>
-__device__ __forceinline__ void k_tile2(f32x4 (&acc)[4][8], char* smem, int slot, long kb_next, const Src4& sa,
-                                        const Src4& sw, int lane_off, int a_rd, int w_rd, int wave) {
-    const char* st = smem + slot * PAIR;
-    bf16x8 wf[4], af[8];
+// Half-tile HALF (rows HALF*128 .. +127) of one operand: DMA instruction i of wave w covers part rows
+// (i*8 + w)*8 .. +7, 8 lanes per 128-byte row.
+template <int HALF>
+__device__ __forceinline__ void stage_half(const Src4& s, long kbyte, char* part_wave) {
+    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[2 * HALF], (lds_ptr)(part_wave + (2 * HALF) * 8192), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[2 * HALF + 1], (lds_ptr)(part_wave + (2 * HALF + 1) * 8192), 16,
+                                     0, 0);
+}
+
+template <int WAIT>
+__device__ __forceinline__ void phase_open() {
+    if (WAIT >= 0) wait_vm<WAIT>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void phase_close() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+// 16 MFMAs: accumulator columns nt0, nt0 + 1 x rows mt0 .. mt0 + 3, both k-halves; fragments [block * 2 + k-half]
+template <int NT0, int MT0>
+__device__ __forceinline__ void quadrant(f32x4 (&acc)[4][8], const bf16x8 (&wf)[4], const bf16x8 (&af)[8]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wf[t] = lds_frag(st + PAIR / 2 + w_rd + t * 2048 + lane_off);
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) af[t] = lds_frag(st + a_rd + t * 2048 + lane_off);
-    if (STAGE_NEXT) {
-        char* nx = smem + (slot ^ 1) * PAIR + wave * 1024;
-        stage_part4(sw, kb_next, nx + PAIR / 2);
-        stage_part4(sa, kb_next, nx);
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[NT0 + nt][MT0 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt * 2 + kh], af[mt * 2 + kh],
+                                                                                  acc[NT0 + nt][MT0 + mt], 0, 0, 0);
+}
+
+// TAIL 0: steady state, 1: next-to-last K-tile (nothing to stage two tiles ahead), 2: last.
+template <int TAIL>
+__device__ __forceinline__ void k_tile64(f32x4 (&acc)[4][8], char* smem, int buf, long kb1, long kb2, const Src4& sa,
+                                         const Src4& sw, int lo0, int lo1, int a_rd, int w_rd, int wave) {
+    const char* cur = smem + buf * PAIR;
+    char* own = smem + buf * PAIR + wave * 1024;
+    char* oth = smem + (buf ^ 1) * PAIR + wave * 1024;
+    const char* ca = cur + a_rd;
+    const char* cw = cur + PAIR / 2 + w_rd;
+    bf16x8 w0[4], w1[4], af[8];
+    // phase 1
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        w0[b * 2] = lds_frag(cw + b * 2048 + lo0);
+        w0[b * 2 + 1] = lds_frag(cw + b * 2048 + lo1);
     }
-    if (WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int b = 0; b < 4; ++b) {
+        af[b * 2] = lds_frag(ca + b * 2048 + lo0);
+        af[b * 2 + 1] = lds_frag(ca + b * 2048 + lo1);
+    }
+    if (TAIL < 2) stage_half<1>(sw, kb1, oth + PAIR / 2);
+    phase_open<TAIL == 2 ? 2 : 8>();
+    quadrant<0, 0>(acc, w0, af);
+    phase_close();
+    // phase 2
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
+    for (int b = 0; b < 2; ++b) {
+        w1[b * 2] = lds_frag(cw + 16384 + b * 2048 + lo0);
+        w1[b * 2 + 1] = lds_frag(cw + 16384 + b * 2048 + lo1);
+    }
+    if (TAIL < 2) stage_half<1>(sa, kb1, oth);
+    phase_open<TAIL == 2 ? 0 : 8>();
+    quadrant<2, 0>(acc, w1, af);
+    phase_close();
+    // phase 3
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        af[b * 2] = lds_frag(ca + 16384 + b * 2048 + lo0);
+        af[b * 2 + 1] = lds_frag(ca + 16384 + b * 2048 + lo1);
+    }
+    if (TAIL == 0) stage_half<0>(sw, kb2, own + PAIR / 2);
+    phase_open<-1>();
+    quadrant<2, 4>(acc, w1, af);
+    phase_close();
+    // phase 4
+    if (TAIL == 0) stage_half<0>(sa, kb2, own);
+    phase_open<TAIL == 0 ? 8 : TAIL == 1 ? 4 : -1>();
+    quadrant<0, 4>(acc, w0, af);
+    phase_close();
 }
 
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
-               const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
-               int M, int N, int K, int tiles_m, int tiles_n, int GM, int wide_store) {
+                const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
+                int M, int N, int K, int tiles_m, int tiles_n, int GM, int wide_store) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    // blocks that share an XCD (same id mod 8) get one contiguous chunk of the tile grid,
-    // walked in groups of 4 tile-rows so that A and W tiles are re-used out of that XCD's L2
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {
@@ -112,7 +176,6 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
     const int tn = (bid % per_group) / gsz;
     const int row0 = tm * TM, col0 = tn * TN;
 
-    // staging: wave w, instruction i covers part rows (i*8 + w)*8 .. +7, 8 lanes per 128-byte row
     Src4 sa, sw;
     sa.base = reinterpret_cast<const char*>(A);
     sw.base = reinterpret_cast<const char*>(W);
@@ -124,9 +187,8 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
         sa.off[i] = (unsigned)ar * (unsigned)lda * 2u + (unsigned)c * 16u;
         sw.off[i] = (unsigned)(col0 + r) * (unsigned)ldw * 2u + (unsigned)c * 16u;
     }
-    // fragment reads: lane (r = lane & 15, q = lane >> 4) reads chunk 4*half + q of row r of a 16-row block
     const int lo0 = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4), lo1 = lo0 ^ 64;
-    const int a_rd = wr * 16384, w_rd = wc * 8192;
+    const int a_rd = wr * 8192, w_rd = wc * 4096;
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -135,29 +197,31 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     char* const wdst = smem + wave * 1024;
-    const int np = K / 64;      // >= 2 (checked on the host)
-    stage_part4(sw, 0, wdst + PAIR / 2);
-    stage_part4(sa, 0, wdst);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int nk = K / 64;      // >= 2 (checked on the host)
+    stage_half<0>(sw, 0, wdst + PAIR / 2);
+    stage_half<0>(sa, 0, wdst);
+    stage_half<1>(sw, 0, wdst + PAIR / 2);
+    stage_half<1>(sa, 0, wdst);
+    stage_half<0>(sw, 128, wdst + PAIR + PAIR / 2);
+    stage_half<0>(sa, 128, wdst + PAIR);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: half a period behind
-    int j = 0;
-    for (; j < np - 1; ++j) {
-        k_tile2<true, false>(acc, smem, j & 1, (long)(j + 1) * 128, sa, sw, lo0, a_rd, w_rd, wave);
-        k_tile2<false, true>(acc, smem, j & 1, 0, sa, sw, lo1, a_rd, w_rd, wave);
-    }
-    k_tile2<false, false>(acc, smem, j & 1, 0, sa, sw, lo0, a_rd, w_rd, wave);
-    k_tile2<false, false>(acc, smem, j & 1, 0, sa, sw, lo1, a_rd, w_rd, wave);
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: one barrier behind
+    int t = 0;
+    for (; t + 2 < nk; ++t)
+        k_tile64<0>(acc, smem, t & 1, (long)(t + 1) * 128, (long)(t + 2) * 128, sa, sw, lo0, lo1, a_rd, w_rd, wave);
+    k_tile64<1>(acc, smem, t & 1, (long)(t + 1) * 128, 0, sa, sw, lo0, lo1, a_rd, w_rd, wave);
+    ++t;
+    k_tile64<2>(acc, smem, t & 1, 0, 0, sa, sw, lo0, lo1, a_rd, w_rd, wave);
     if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
 
-    // epilogue: lane holds out[m][n..n+3], m = row0 + wr*128 + mt*16 + fr, n = col0 + wc*64 + nt*16 + fq*4.
-    // Rows outermost: the four stores of a lane for one row are the four 32-byte quarters of
-    // one 128-byte line (64 bf16 columns), issued back to back so that they merge on the way out.
+    // epilogue: lane holds out[m][n .. n+3],
+    //   m = row0 + (mt >> 2) * 128 + wr * 64 + (mt & 3) * 16 + fr,  n = col0 + (nt >> 1) * 128 + wc * 32 + (nt & 1) * 16 + fq * 4
     const int fr = lane & 15, fq = lane >> 4;
     float bv[4][4], gv[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int n = col0 + wc * 64 + nt * 16 + fq * 4;
+        const int n = col0 + (nt >> 1) * 128 + wc * 32 + (nt & 1) * 16 + fq * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bv[nt][j] = 0.f;
@@ -176,19 +240,13 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
         }
     }
     if ((EPI == EPI_BF16 || EPI == EPI_BF16_GELU) && wide_store) {
-        // bf16 output through LDS: the ring is free (every wave is past the last barrier and every
-        // DMA has landed), each wave owns 16 KiB of it for its 128 x 64 tile = 128 rows of 128 B.
-        // Written in the accumulator layout (8 B per lane), read back 16 B per lane so that one
-        // store instruction covers 8 full 128-byte lines.  16-byte chunk c of row r sits at chunk
-        // c ^ ((r >> 1) & 7): the writes are 2 lanes per bank (the minimum for 512 B), the reads
-        // conflict-free.
-        char* ep = smem + wave * 16384;
-        const int rr = lane >> 3, cc = lane & 7;
-        bf16_t* ob = reinterpret_cast<bf16_t*>(out) + (long)(row0 + wr * 128) * ldo + col0 + wc * 64 + cc * 8;
-        // two halves of 64 rows: the stores of the first half are in flight while the second half is
-        // being computed (the GELU is ~40 VALU cycles per element)
+        // bf16 output through LDS, one 128-row half of the tile per ring buffer (64 KiB = 128 rows of 512 B):
+        // written in the accumulator layout (8 B per lane), read back 16 B per lane so that 32 lanes store one
+        // whole 512-byte row segment.  16-byte chunk c of row r sits at chunk c ^ (r & 15): conflict-free both ways.
+        bf16_t* ob = reinterpret_cast<bf16_t*>(out) + (long)row0 * ldo + col0 + (lane & 31) * 8;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
+            char* img = smem + hf * PAIR;
 #pragma unroll
             for (int mt = 4 * hf; mt < 4 * hf + 4; ++mt)
 #pragma unroll
@@ -203,25 +261,27 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
                     uint2 o;
                     o.x = pack_bf2(y[0], y[1]);
                     o.y = pack_bf2(y[2], y[3]);
-                    const int r = mt * 16 + fr, c = nt * 2 + (fq >> 1);
-                    *reinterpret_cast<uint2*>(ep + r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + (fq & 1) * 8) = o;
+                    const int r = wr * 64 + (mt & 3) * 16 + fr;
+                    const int c = (nt >> 1) * 16 + wc * 4 + (nt & 1) * 2 + (fq >> 1);
+                    *reinterpret_cast<uint2*>(img + r * 512 + ((c ^ fr) << 4) + (fq & 1) * 8) = o;
                 }
+            __syncthreads();
 #pragma unroll
-            for (int i = 8 * hf; i < 8 * hf + 8; ++i) {
-                const int r = i * 8 + rr;
-                const uint4 v = *reinterpret_cast<const uint4*>(ep + r * 128 + ((cc ^ ((r >> 1) & 7)) << 4));
-                if (row0 + wr * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)r * ldo) = v;
+            for (int i = 0; i < 8; ++i) {
+                const int r = i * 16 + wave * 2 + (lane >> 5);
+                const uint4 v = *reinterpret_cast<const uint4*>(img + r * 512 + (((lane & 31) ^ (r & 15)) << 4));
+                if (row0 + hf * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)(hf * 128 + r) * ldo) = v;
             }
         }
         return;
     }
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
-        const int m = row0 + wr * 128 + mt * 16 + fr;
+        const int m = row0 + (mt >> 2) * 128 + wr * 64 + (mt & 3) * 16 + fr;
         if (m >= M) continue;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int n = col0 + wc * 64 + nt * 16 + fq * 4;
+            const int n = col0 + (nt >> 1) * 128 + wc * 32 + (nt & 1) * 16 + fq * 4;
             float y[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = acc[nt][mt][j] + bv[nt][j];
@@ -256,7 +316,7 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
 bool ovd_gemm256_applicable(long lda, long ldw, int M, int N, int K) {
     // one workgroup per CU: worth it from about two rounds of 256 x 256 tiles over the 256 CUs
     const long tiles = (long)ceil_div(M, TM) * (N / TN);
-    return N % TN == 0 && K % (2 * TK) == 0 && K >= 4 * TK && M >= 2 * TM && tiles >= 512 &&
+    return N % TN == 0 && K % KT == 0 && K >= 2 * KT && M >= 2 * TM && tiles >= 512 &&
            (long)M * lda * 2 < (1L << 32) && (long)N * ldw * 2 < (1L << 32);
 }
 

@@ -188,6 +188,18 @@ if __name__ == "__main__":
         gemm(777, 256, 192, 3, check=True)
         gemm(4096, 1536, 1536, 1, check=True)
         gemm(40560, 1536, 1536, 2, check=True)
+    if "gemmshapes" in args.what:   # the five Linear shapes of the cfg2 model on the library as loaded
+        M = 40560
+        line = []
+        for (N, K, epi) in ((4608, 1536, 0), (1536, 1536, 0), (8960, 1536, 1), (1536, 8960, 0), (1536, 8960, 3)):
+            a = torch.randn(M, K, device="cuda").to(BF16)
+            w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF16)
+            b = torch.randn(N, device="cuda").to(BF16)
+            out = torch.zeros(M, N, device="cuda", dtype=BF16 if epi < 2 else torch.float32)
+            t = min(timeit(lambda: H.gemm(a, w, out, b, epi), iters=20) for _ in range(3))
+            line.append(f"N{N}K{K}e{epi} {2.0 * M * N * K / 1e9 / t:.0f}")
+            del a, w, out
+        print(os.environ.get("OVD_LIB_PATH", "default").split("/")[-1], " | ".join(line), flush=True)
     if "gemmsq" in args.what:
         gemm(4096, 4096, 4096, 0, uniform=True)
         gemm(8192, 8192, 8192, 0, uniform=True)
