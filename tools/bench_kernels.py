@@ -200,6 +200,50 @@ if __name__ == "__main__":
             line.append(f"N{N}K{K}e{epi} {2.0 * M * N * K / 1e9 / t:.0f}")
             del a, w, out
         print(os.environ.get("OVD_LIB_PATH", "default").split("/")[-1], " | ".join(line), flush=True)
+    if "twostream" in args.what:    # does a second stream's kernel fill the partly empty last round of tiles?
+        C, F, L = 1536, 8960, 20280
+        def layer_ops(M, tag):
+            x = torch.randn(M, C, device="cuda").to(BF16)
+            wq = (torch.randn(3 * C, C, device="cuda") / 40).to(BF16)
+            wo = (torch.randn(C, C, device="cuda") / 40).to(BF16)
+            w1 = (torch.randn(F, C, device="cuda") / 40).to(BF16)
+            w2 = (torch.randn(C, F, device="cuda") / 90).to(BF16)
+            qkv = torch.empty(M, 3 * C, device="cuda", dtype=BF16)
+            o = torch.empty(M, C, device="cuda", dtype=BF16)
+            h = torch.empty(M, F, device="cuda", dtype=BF16)
+            B = M // L
+            att = torch.empty(B, L, 12, 128, device="cuda", dtype=BF16)
+            def run():
+                H.gemm(x, wq, qkv, None, 0)
+                q5 = qkv.view(B, L, 3, 12, 128)
+                H.flash_attn(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], att)
+                H.gemm(att.view(M, C), wo, o, None, 0)
+                H.gemm(o, wo, x, None, 0)
+                H.gemm(x, wo, o, None, 0)
+                H.gemm(o, w1, h, None, 1)
+                H.gemm(h, w2, x, None, 0)
+            return run
+        both = layer_ops(2 * L, "both")
+        a, b = layer_ops(L, "a"), layer_ops(L, "b")
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        def two():
+            cur = torch.cuda.current_stream()
+            s1.wait_stream(cur); s2.wait_stream(cur)
+            with torch.cuda.stream(s1):
+                a()
+            with torch.cuda.stream(s2):
+                b()
+            cur.wait_stream(s1); cur.wait_stream(s2)
+        def seq():
+            a(); b()
+        for name, fn in (("one stream, both branches batched", both), ("one stream, branch after branch", seq),
+                         ("two streams, one branch each", two)):
+            g = torch.cuda.CUDAGraph()
+            fn(); torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                fn()
+            ms = min(timeit(g.replay, iters=10) for _ in range(3))
+            print(f"layer GEMMs + self-attention, {name}: {ms:.3f} ms", flush=True)
     if "gemmsq" in args.what:
         gemm(4096, 4096, 4096, 0, uniform=True)
         gemm(8192, 8192, 8192, 0, uniform=True)
