@@ -10,11 +10,12 @@
 //                           quantisation fused into its write pass
 //   gemm_fp8_kernel<EPI>    out = epilogue((sum_k A8[m][k] W8[n][k]) * sa[m] * sw[n] + bias[n])
 //
-// The GEMM is the 256 x 256 ring-pipelined kernel of gemm256.hip with the K-tile kept at 64
-// BYTES per row: the DMA, the LDS image and its swizzle, the counted waits and the half-phase
-// stagger of the two wave groups are byte-identical; a K-tile now holds 64 k-values and is
-// consumed by 8 v_mfma_scale_f32_32x32x64_f8f6f4 per wave (unit block scales), which take the
-// time of the 32 bf16 MFMAs they replace for twice the K.
+// Two GEMM loops on the 256 x 256 tile of gemm256.hip.  K % 128 == 0 (every layer of both models):
+// gemm_fp8p_kernel, that file's four-phase schedule on K-tiles of 128 bytes per row - the DMA, the LDS
+// image and its swizzle, the counted waits and the one-barrier stagger of the two wave groups are
+// byte-identical; a phase is 4 v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), the matrix time of
+// the 16 bf16 MFMAs it replaces for twice the K.  Other K (multiples of 64): gemm_fp8_kernel, a ring of four
+// K-tiles of 64 bytes per row, 8 MFMAs per K-tile and wave, vmcnt(4).
 #include "ln_row.h"
 
 namespace {
@@ -281,7 +282,7 @@ gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict
                     uint2 o;
                     o.x = pack_bf2(y[0], y[1]);
                     o.y = pack_bf2(y[2], y[3]);
-                    if (staged) {      // rows of 128 B, 16-byte chunk c at c ^ ((r >> 1) & 7), as in gemm256.hip
+                    if (staged) {      // rows of 128 B, 16-byte chunk c at c ^ ((r >> 1) & 7)
                         const int r = mt * 32 + fr, c = nt * 4 + g;
                         *reinterpret_cast<uint2*>(ep + r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + fh * 8) = o;
                     } else {
@@ -328,6 +329,289 @@ gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict
             const int sw = OB == 2 ? ((r >> 1) & 7) : ((r >> 2) & 3);
             const uint4 v = *reinterpret_cast<const uint4*>(ep + r * ROWB + ((cc ^ sw) << 4));
             if (row0 + wr * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)r * ldo * OB) = v;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------ GEMM, phase-pipelined loop
+// The schedule of gemm256.hip on e4m3 operands, for K % 128 == 0: K-tiles of 128 BYTES per row (the same
+// LDS image: two buffers of 64 KiB, A part | W part, 256 rows of 128 B, chunk c of row r at c ^ ((r>>1)&7)),
+// four phases per K-tile, one 16 KiB half-tile staged per phase, vmcnt(8), the two wave groups one barrier
+// apart.  Wave (wr, wc) owns rows {wr*64 .. +63} of both A halves and weight rows {wc*32 .. +31} of both W
+// halves; a phase is 4 v_mfma_scale_f32_32x32x64_f8f6f4 (2 row blocks x 2 k-steps of 64), the matrix time of
+// the 16 bf16 MFMAs of that kernel's phase for twice the K.
+constexpr int PBUF = 2 * 256 * 128;     // one buffer: A part 32 KiB | W part 32 KiB
+
+struct Src4 {
+    const char* base;
+    unsigned off[4];
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+template <int HALF>
+__device__ __forceinline__ void stage_half(const Src4& s, long kbyte, char* part_wave) {
+    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[2 * HALF], (lds_ptr)(part_wave + (2 * HALF) * 8192), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(s.base + kbyte + s.off[2 * HALF + 1], (lds_ptr)(part_wave + (2 * HALF + 1) * 8192), 16,
+                                     0, 0);
+}
+
+template <int WAIT>
+__device__ __forceinline__ void phase_open8() {
+    if (WAIT >= 0) wait_vm<WAIT>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void phase_close8() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+// fragment of a 32-row block for k-step ks: lane (r = lane & 31, h = lane >> 5) takes bytes 64*ks + 32h .. +31
+// of row r = chunks 4*ks + 2h and 4*ks + 2h + 1 (o[ks][0], o[ks][1]: swizzled byte offsets inside the block)
+struct FragOff {
+    int o[2][2];
+};
+__device__ __forceinline__ i32x8 lds_frag8p(const char* blk, const FragOff& f, int ks) {
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(blk + f.o[ks][0]);
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(blk + f.o[ks][1]);
+    return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// 4 MFMAs: weight block wf (both k-steps) x the two row blocks of one A half; accumulators acc[NH][MB0], acc[NH][MB0 + 1]
+template <int NH, int MB0>
+__device__ __forceinline__ void quadrant8(f32x16 (&acc)[2][4], const i32x8 (&wf)[2], const i32x8 (&af)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+            acc[NH][MB0 + mb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[ks], af[mb * 2 + ks], acc[NH][MB0 + mb], 0,
+                                                                              0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+// TAIL 0: steady state, 1: next-to-last K-tile, 2: last (see gemm256.hip for the schedule and its hazards)
+template <int TAIL>
+__device__ __forceinline__ void k_tile128(f32x16 (&acc)[2][4], char* smem, int buf, long kb1, long kb2, const Src4& sa,
+                                          const Src4& sw, const FragOff& fo, int a_rd, int w_rd, int wave) {
+    const char* cur = smem + buf * PBUF;
+    char* own = smem + buf * PBUF + wave * 1024;
+    char* oth = smem + (buf ^ 1) * PBUF + wave * 1024;
+    const char* ca = cur + a_rd;
+    const char* cw = cur + PBUF / 2 + w_rd;
+    i32x8 w0[2], w1[2], af[4];       // [k-step]; [row block * 2 + k-step]
+    // phase 1
+    w0[0] = lds_frag8p(cw, fo, 0);
+    w0[1] = lds_frag8p(cw, fo, 1);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        af[b * 2] = lds_frag8p(ca + b * 4096, fo, 0);
+        af[b * 2 + 1] = lds_frag8p(ca + b * 4096, fo, 1);
+    }
+    if (TAIL < 2) stage_half<1>(sw, kb1, oth + PBUF / 2);
+    phase_open8<TAIL == 2 ? 2 : 8>();
+    quadrant8<0, 0>(acc, w0, af);
+    phase_close8();
+    // phase 2
+    w1[0] = lds_frag8p(cw + 16384, fo, 0);
+    w1[1] = lds_frag8p(cw + 16384, fo, 1);
+    if (TAIL < 2) stage_half<1>(sa, kb1, oth);
+    phase_open8<TAIL == 2 ? 0 : 8>();
+    quadrant8<1, 0>(acc, w1, af);
+    phase_close8();
+    // phase 3
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        af[b * 2] = lds_frag8p(ca + 16384 + b * 4096, fo, 0);
+        af[b * 2 + 1] = lds_frag8p(ca + 16384 + b * 4096, fo, 1);
+    }
+    if (TAIL == 0) stage_half<0>(sw, kb2, own + PBUF / 2);
+    phase_open8<-1>();
+    quadrant8<1, 2>(acc, w1, af);
+    phase_close8();
+    // phase 4
+    if (TAIL == 0) stage_half<0>(sa, kb2, own);
+    phase_open8<TAIL == 0 ? 8 : TAIL == 1 ? 4 : -1>();
+    quadrant8<0, 2>(acc, w0, af);
+    if (TAIL != 0) {
+        // the last K-tiles run straight into the epilogue: without a use here hipcc sinks their MFMAs past the
+        // closing barriers to the accumulators' first use (and spills the fragments it then has to keep)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]));
+    }
+    phase_close8();
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm_fp8p_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict__ a_scale, float a_scale_all,
+                 const uint8_t* __restrict__ W, long ldw, const float* __restrict__ w_scale,
+                 const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
+                 float out_inv_scale, int M, int N, int K, int tiles_m, int tiles_n, int GM, int wide_store) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group;
+    const int first_m = grp * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + (bid % per_group) % gsz;
+    const int tn = (bid % per_group) / gsz;
+    const int row0 = tm * TM, col0 = tn * TN;
+
+    Src4 sa, sw;
+    sa.base = reinterpret_cast<const char*>(A);
+    sw.base = reinterpret_cast<const char*>(W);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int ar = min(row0 + r, M - 1);
+        sa.off[i] = (unsigned)ar * (unsigned)lda + (unsigned)c * 16u;
+        sw.off[i] = (unsigned)(col0 + r) * (unsigned)ldw + (unsigned)c * 16u;
+    }
+    const int fr = lane & 31, fh = lane >> 5;
+    FragOff fo;
+    {
+        const int swz = (fr >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fo.o[ks][j] = fr * 128 + (((4 * ks + 2 * fh + j) ^ swz) << 4);
+    }
+    const int a_rd = wr * 8192, w_rd = wc * 4096;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    char* const wdst = smem + wave * 1024;
+    const int nk = K / 128;      // >= 2 (checked on the host)
+    stage_half<0>(sw, 0, wdst + PBUF / 2);
+    stage_half<0>(sa, 0, wdst);
+    stage_half<1>(sw, 0, wdst + PBUF / 2);
+    stage_half<1>(sa, 0, wdst);
+    stage_half<0>(sw, 128, wdst + PBUF + PBUF / 2);
+    stage_half<0>(sa, 128, wdst + PBUF);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // second half of the waves: one barrier behind
+    int t = 0;
+    for (; t + 2 < nk; ++t)
+        k_tile128<0>(acc, smem, t & 1, (long)(t + 1) * 128, (long)(t + 2) * 128, sa, sw, fo, a_rd, w_rd, wave);
+    k_tile128<1>(acc, smem, t & 1, (long)(t + 1) * 128, 0, sa, sw, fo, a_rd, w_rd, wave);
+    ++t;
+    k_tile128<2>(acc, smem, t & 1, 0, 0, sa, sw, fo, a_rd, w_rd, wave);
+    if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
+    asm volatile("" ::: "memory");                        // keeps the epilogue's scale / bias loads out of the last K-tile
+
+    // epilogue: acc[nh][mh*2 + mb] register 4g + j is out[m][n + j],
+    //   m = row0 + mh*128 + wr*64 + mb*32 + (lane & 31),  n = col0 + nh*128 + wc*32 + 8g + 4*(lane >> 5)
+    constexpr bool NARROW_OUT = EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_FP8_GELU;
+    constexpr int OB = EPI == EPI_FP8_GELU ? 1 : 2;            // bytes per output element on the staged path
+    constexpr int ROWB = 256 * OB;                             // bytes per tile row in the staged image
+    const bool staged = NARROW_OUT && wide_store;
+    // staged: one 128-row half of the tile per LDS buffer, rows of ROWB bytes, 16-byte chunk c of row r at
+    // c ^ (r & 15); read back 16 B per lane so that ROWB / 16 lanes store one whole row segment
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+        char* img = smem + mh * PBUF;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int rl = wr * 64 + mb * 32 + fr;              // row inside the half
+            const int m = row0 + mh * 128 + rl;
+            if (!staged && m >= M) continue;
+            const float sa_m = (a_scale ? a_scale[min(m, M - 1)] : 1.f) * a_scale_all;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = nh * 128 + wc * 32 + 8 * g + 4 * fh;      // column inside the tile
+                    const int n = col0 + nl;
+                    const f32x16& a16 = acc[nh][mh * 2 + mb];
+                    const float4 ws = *reinterpret_cast<const float4*>(w_scale + n);
+                    float y[4] = {a16[4 * g] * (sa_m * ws.x), a16[4 * g + 1] * (sa_m * ws.y),
+                                  a16[4 * g + 2] * (sa_m * ws.z), a16[4 * g + 3] * (sa_m * ws.w)};
+                    if (bias) {
+                        const uint2 bp = *reinterpret_cast<const uint2*>(bias + n);
+                        y[0] += bf2f(bp.x & 0xffff);
+                        y[1] += bf2f(bp.x >> 16);
+                        y[2] += bf2f(bp.y & 0xffff);
+                        y[3] += bf2f(bp.y >> 16);
+                    }
+                    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+                        if (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(round_bf(y[j]));
+                        }
+                        uint2 o;
+                        o.x = pack_bf2(y[0], y[1]);
+                        o.y = pack_bf2(y[2], y[3]);
+                        if (staged) {
+                            const int c = nl >> 3;
+                            *reinterpret_cast<uint2*>(img + rl * ROWB + ((c ^ (rl & 15)) << 4) + fh * 8) = o;
+                        } else {
+                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)m * ldo + n) = o;
+                        }
+                    } else if (EPI == EPI_FP8_GELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = round_bf(gelu_tanh_f(round_bf(y[j]))) * out_inv_scale;
+                        const uint32_t o = pack_fp8x4(y[0], y[1], y[2], y[3]);
+                        if (staged) {
+                            const int c = nl >> 4;
+                            *reinterpret_cast<uint32_t*>(img + rl * ROWB + ((c ^ (rl & 15)) << 4) + (nl & 15)) = o;
+                        } else {
+                            *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + (long)m * ldo + n) = o;
+                        }
+                    } else if (EPI == EPI_F32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)m * ldo + n) =
+                            make_float4(round_bf(y[0]), round_bf(y[1]), round_bf(y[2]), round_bf(y[3]));
+                    } else {
+                        float gv[4] = {1.f, 1.f, 1.f, 1.f};
+                        if (gate) {
+                            const float4 g4 = *reinterpret_cast<const float4*>(gate + n);
+                            gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+                        }
+                        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)m * ldo + n);
+                        float4 x = *p;
+                        x.x += round_bf(y[0]) * gv[0];
+                        x.y += round_bf(y[1]) * gv[1];
+                        x.z += round_bf(y[2]) * gv[2];
+                        x.w += round_bf(y[3]) * gv[3];
+                        *p = x;
+                    }
+                }
+        }
+        if (staged) {       // uniform: every thread reaches the barrier
+            __syncthreads();
+            constexpr int CPR = ROWB / 16, RPI = 512 / CPR;       // chunks per row; rows per pass of the workgroup
+            const int rr = tid / CPR, cc = tid % CPR;
+            char* ob = reinterpret_cast<char*>(out) + ((long)(row0 + mh * 128) * ldo + col0) * OB + cc * 16;
+#pragma unroll
+            for (int i = 0; i < 128 / RPI; ++i) {
+                const int r = i * RPI + rr;
+                const uint4 v = *reinterpret_cast<const uint4*>(img + r * ROWB + ((cc ^ (r & 15)) << 4));
+                if (row0 + mh * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)r * ldo * OB) = v;
+            }
         }
     }
 }
@@ -395,8 +679,11 @@ int ovd_impl_gemm_fp8(const uint8_t* A, long lda, const float* a_scale, float a_
     OVD_REQUIRE(out_scale > 0.f && a_scale_all > 0.f, "gemm_fp8: scales must be positive");
     const int tiles_m = ceil_div(M, TM), tiles_n = N / TN;
     dim3 grid(tiles_m * tiles_n), blk(512);
-    const size_t lds = NSTAGE * STAGE;
+    const size_t lds = NSTAGE * STAGE;          // = 2 * PBUF: both loops use 128 KiB
     const float out_inv = 1.f / out_scale;
+    // K-tiles of 128 bytes in four phases where K allows it, the ring of 64-byte K-tiles otherwise
+    static std::atomic<int> ring_cache{INT32_MIN};
+    const bool phased = K % 128 == 0 && K >= 256 && ovd_env_int(ring_cache, "OVD_FP8_RING", 0) == 0;
     // 16-byte output stores (bf16 and e4m3 epilogues) need 16-byte aligned rows
     const long row_bytes = ldo * (epilogue == EPI_FP8_GELU ? 1 : 2);
     const int wide = (row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
@@ -405,8 +692,15 @@ int ovd_impl_gemm_fp8(const uint8_t* A, long lda, const float* a_scale, float a_
         static OvdLdsLimit lim;                                                                           \
         if (!lim.ensure(reinterpret_cast<const void*>(&gemm_fp8_kernel<E>), lds))                         \
             OVD_FAIL("gemm_fp8: cannot reserve %zu bytes of LDS", lds);                                    \
-        hipLaunchKernelGGL((gemm_fp8_kernel<E>), grid, blk, lds, st, A, lda, a_scale, a_scale_all, W, ldw, \
-                           w_scale, bias, out, ldo, gate, out_inv, M, N, K, tiles_m, tiles_n, 4, wide);   \
+        static OvdLdsLimit limp;                                                                          \
+        if (!limp.ensure(reinterpret_cast<const void*>(&gemm_fp8p_kernel<E>), lds))                       \
+            OVD_FAIL("gemm_fp8: cannot reserve %zu bytes of LDS", lds);                                    \
+        if (phased)                                                                                       \
+            hipLaunchKernelGGL((gemm_fp8p_kernel<E>), grid, blk, lds, st, A, lda, a_scale, a_scale_all, W, ldw, \
+                               w_scale, bias, out, ldo, gate, out_inv, M, N, K, tiles_m, tiles_n, 4, wide); \
+        else                                                                                              \
+            hipLaunchKernelGGL((gemm_fp8_kernel<E>), grid, blk, lds, st, A, lda, a_scale, a_scale_all, W, ldw, \
+                               w_scale, bias, out, ldo, gate, out_inv, M, N, K, tiles_m, tiles_n, 4, wide); \
     } break;
     switch (epilogue) {
         GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) GEMM_CASE(EPI_FP8_GELU)

@@ -1,0 +1,110 @@
+"""The GEMM loops order their LDS reads, DMA, counted waits, barriers and MFMAs by hand; nothing in the
+language stops the compiler from moving register-only MFMAs or LDS reads across a bare s_barrier.  These
+tests compile the kernels to gfx950 assembly (no GPU needed) and check the instruction order of the
+steady-state loop and of the two peeled K-tiles behind it."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "omni-video_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+KINDS = ("v_mfma", "s_barrier", "ds_read", "s_waitcnt", "global_load_lds", "scratch_")
+
+
+def listing(src, tmp_path):
+    out = tmp_path / (src + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-S", "--cuda-device-only",
+                    os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True)
+    return out.read_text()
+
+
+def kernels(text, name):
+    """{mangled name: body} for every instantiation of `name`."""
+    found = {}
+    for m in re.finditer(r"^(_ZN\S*%s\S*):\s" % name, text, re.M):
+        end = text.index(".end_amdhsa_kernel", m.end()) if ".end_amdhsa_kernel" in text[m.end():] else len(text)
+        body = text[m.end():end]
+        found[m.group(1)] = body[:body.index("s_endpgm")] if "s_endpgm" in body else body
+    return found
+
+
+def runs(lines):
+    """Run-length sequence of the instruction kinds that matter, e.g. ['12 ds_read', '2 global_load_lds', ...]."""
+    seq = []
+    for ln in lines:
+        ln = ln.split(";")[0].strip()
+        if not ln or ln.endswith(":") or ln.startswith("."):
+            continue
+        op = ln.split()[0]
+        kind = next((k for k in KINDS if op.startswith(k)), None)
+        if kind is None:
+            continue
+        if seq and seq[-1][1] == kind:
+            seq[-1][0] += 1
+        else:
+            seq.append([1, kind])
+    return [f"{n} {k}" for n, k in seq]
+
+
+def loop_and_tail(body):
+    lines = body.split("\n")
+    head = next(i for i, l in enumerate(lines) if "Inner Loop Header" in l)
+    back = next(i for i in range(head, len(lines)) if "s_cbranch_scc1" in lines[i])
+    labels = [i for i in range(back, len(lines)) if re.match(r"\.LBB\d+_\d+:", lines[i])]
+    return runs(lines[head:back + 1]), runs(lines[back + 1:labels[1]])
+
+
+def phase(reads, dma, wait, mfma):
+    out = []
+    if reads:
+        out.append(f"{reads} ds_read")
+    if dma:
+        out.append("2 global_load_lds")
+    if wait:
+        out.append("1 s_waitcnt")          # counted vmcnt in front of the barrier
+    out.append("1 s_barrier")
+    if reads:
+        out.append("1 s_waitcnt")          # lgkmcnt behind it
+    out += [f"{mfma} v_mfma", "1 s_barrier"]
+    return out
+
+
+def merge(seq):
+    """Adjacent equal kinds of consecutive phases (two s_barrier in a row) merge in the run-length form."""
+    out = []
+    for item in seq:
+        n, k = item.split(" ", 1)
+        if out and out[-1][1] == k:
+            out[-1][0] += int(n)
+        else:
+            out.append([int(n), k])
+    return [f"{n} {k}" for n, k in out]
+
+
+def expected(mfma):
+    steady = phase(12, True, True, mfma) + phase(4, True, True, mfma) + phase(8, True, False, mfma) + \
+        phase(0, True, True, mfma)
+    penult = phase(12, True, True, mfma) + phase(4, True, True, mfma) + phase(8, False, False, mfma) + \
+        phase(0, False, True, mfma)
+    last = phase(12, False, True, mfma) + phase(4, False, True, mfma) + phase(8, False, False, mfma) + \
+        phase(0, False, False, mfma)
+    # one more barrier closes the loop for the wave group that started first
+    return merge(steady), merge(penult + last + ["1 s_barrier"])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+@pytest.mark.parametrize("src,kernel,mfma,count", [("gemm256.hip", "gemm256_kernel", 16, 4),
+                                                   ("fp8.hip", "gemm_fp8p_kernel", 4, 5)])
+def test_phased_gemm_loop_keeps_its_order(tmp_path, src, kernel, mfma, count):
+    ks = kernels(listing(src, tmp_path), kernel)
+    assert len(ks) == count, sorted(ks)
+    want_loop, want_tail = expected(mfma)
+    for name, body in ks.items():
+        assert "scratch_" not in body, f"{name}: register spills"
+        loop, tail = loop_and_tail(body)
+        assert loop == want_loop, (name, loop)
+        assert tail == want_tail, (name, tail)
