@@ -449,23 +449,22 @@ __device__ __forceinline__ void k_tile128(f32x16 (&acc)[2][4], char* smem, int b
     phase_close8();
 }
 
+// One 256 x 256 output tile: `bid` is the tile's position in the XCD-ordered walk.
 template <int EPI>
-__global__ void __launch_bounds__(512, 2)
-gemm_fp8p_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict__ a_scale, float a_scale_all,
-                 const uint8_t* __restrict__ W, long ldw, const float* __restrict__ w_scale,
-                 const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
-                 float out_inv_scale, int M, int N, int K, int tiles_m, int tiles_n, int GM, int wide_store) {
+__device__ __forceinline__ void
+gemm_fp8p_tile(const uint8_t* __restrict__ A, long lda, const float* __restrict__ a_scale, float a_scale_all,
+               const uint8_t* __restrict__ W, long ldw, const float* __restrict__ w_scale,
+               const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
+               float out_inv_scale, int M, int N, int K, int tiles_m, int tiles_n, int GM, int wide_store, int bid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    // per-lane values are derived again for every tile: hoisted out of the tile loop they outlive the K-loop
+    // and hipcc spills them
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
     const int per_group = GM * tiles_n;
     const int grp = bid / per_group;
     const int first_m = grp * GM;
@@ -616,6 +615,27 @@ gemm_fp8p_kernel(const uint8_t* __restrict__ A, long lda, const float* __restric
     }
 }
 
+
+// Persistent launch, one workgroup per CU, as gemm256_kernel: the workgroups of an XCD take the tiles of that
+// XCD's chunk of the walk round by round.
+template <int EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm_fp8p_kernel(const uint8_t* __restrict__ A, long lda, const float* __restrict__ a_scale, float a_scale_all,
+                 const uint8_t* __restrict__ W, long ldw, const float* __restrict__ w_scale,
+                 const bf16_t* __restrict__ bias, void* __restrict__ out, long ldo, const float* __restrict__ gate,
+                 float out_inv_scale, int M, int N, int K, int tiles_m, int tiles_n, int GM, int wide_store) {
+    const int nwg = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int count = q + (xcd < r ? 1 : 0);
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    for (int t = blockIdx.x >> 3; t < count; t += per_xcd) {
+        gemm_fp8p_tile<EPI>(A, lda, a_scale, a_scale_all, W, ldw, w_scale, bias, out, ldo, gate, out_inv_scale, M, N, K,
+                            tiles_m, tiles_n, GM, wide_store, first + t);
+        __syncthreads();          // the LDS buffers are staged again by the next tile
+    }
+}
+
 }  // namespace
 
 int ovd_impl_quant_rows_fp8(const bf16_t* x, long ldx, uint8_t* q, long ldq, float* scale, int M, int K,
@@ -684,6 +704,11 @@ int ovd_impl_gemm_fp8(const uint8_t* A, long lda, const float* a_scale, float a_
     // K-tiles of 128 bytes in four phases where K allows it, the ring of 64-byte K-tiles otherwise
     static std::atomic<int> ring_cache{INT32_MIN};
     const bool phased = K % 128 == 0 && K >= 256 && ovd_env_int(ring_cache, "OVD_FP8_RING", 0) == 0;
+    // the phased kernel is persistent: one workgroup per CU when there are more tiles than that (a multiple of 8,
+    // so that every XCD gets the same number), one per tile otherwise
+    static std::atomic<int> persist_cache{INT32_MIN};
+    const int cus = ovd_env_int(persist_cache, "OVD_GEMM_PERSIST", 1) ? max(8, ovd_device_cus() / 8 * 8) : 1 << 30;
+    const dim3 pgrid(min(tiles_m * tiles_n, cus));
     // 16-byte output stores (bf16 and e4m3 epilogues) need 16-byte aligned rows
     const long row_bytes = ldo * (epilogue == EPI_FP8_GELU ? 1 : 2);
     const int wide = (row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
@@ -696,7 +721,7 @@ int ovd_impl_gemm_fp8(const uint8_t* A, long lda, const float* a_scale, float a_
         if (!limp.ensure(reinterpret_cast<const void*>(&gemm_fp8p_kernel<E>), lds))                       \
             OVD_FAIL("gemm_fp8: cannot reserve %zu bytes of LDS", lds);                                    \
         if (phased)                                                                                       \
-            hipLaunchKernelGGL((gemm_fp8p_kernel<E>), grid, blk, lds, st, A, lda, a_scale, a_scale_all, W, ldw, \
+            hipLaunchKernelGGL((gemm_fp8p_kernel<E>), pgrid, blk, lds, st, A, lda, a_scale, a_scale_all, W, ldw, \
                                w_scale, bias, out, ldo, gate, out_inv, M, N, K, tiles_m, tiles_n, 4, wide); \
         else                                                                                              \
             hipLaunchKernelGGL((gemm_fp8_kernel<E>), grid, blk, lds, st, A, lda, a_scale, a_scale_all, W, ldw, \

@@ -54,8 +54,15 @@ def loop_and_tail(body):
     lines = body.split("\n")
     head = next(i for i, l in enumerate(lines) if "Inner Loop Header" in l)
     back = next(i for i in range(head, len(lines)) if "s_cbranch_scc1" in lines[i])
-    labels = [i for i in range(back, len(lines)) if re.match(r"\.LBB\d+_\d+:", lines[i])]
-    return runs(lines[head:back + 1]), runs(lines[back + 1:labels[1]])
+    # the two peeled K-tiles: from the loop's back branch to the last MFMA and the barriers that close it
+    last = max(i for i in range(back, len(lines)) if lines[i].split(";")[0].strip().startswith("v_mfma"))
+    end = last + 1
+    while end < len(lines):
+        op = lines[end].split(";")[0].strip().split()
+        if op and any(op[0].startswith(k) for k in KINDS) and not op[0].startswith("s_barrier"):
+            break
+        end += 1
+    return runs(lines[head:back + 1]), runs(lines[back + 1:end])
 
 
 def phase(reads, dma, wait, mfma):
