@@ -347,6 +347,32 @@ def main():
         roof2 = {"bound": "mfma", "kernel": "gemm256_kernel<GELU> (FFN-up, one layer)", "achieved": round(fl2 / ms2 / 1e9, 1),
                  "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl2 / ms2 / 1e9 / PEAK_BF16_TFLOPS, 4),
                  "median_launch_ms": round(ms2, 4), "flop_per_launch": fl2}
+        # all six linear layers of one block, each on the step's own buffers (median of 10 launches each)
+        Mrows, C, F = eng.h.shape[0], cfg["dim"], cfg["ffn_dim"]
+        qkv2, att2 = eng.qkv.view(Mrows, 3 * C), eng.att.view(Mrows, C)
+        calls = {
+            "qkv": (lambda: H.gemm(eng.h, Lw["w_qkv"], qkv2, Lw["b_qkv"], H.EPI_BF16), 2.0 * Mrows * 3 * C * C),
+            "o": (lambda: H.gemm(att2, Lw["w_o"], eng.res, Lw["b_o"], H.EPI_BF16), 2.0 * Mrows * C * C),
+            "cross_q": (lambda: H.gemm(eng.h, Lw["w_cq"], qkv2[:, :C], Lw["b_cq"], H.EPI_BF16), 2.0 * Mrows * C * C),
+            "cross_o": (lambda: H.gemm(att2, Lw["w_co"], eng.res, Lw["b_co"], H.EPI_BF16), 2.0 * Mrows * C * C),
+            "ffn_up_gelu": (lambda: H.gemm(eng.h, Lw["w_f0"], eng.ffn, Lw["b_f0"], H.EPI_BF16_GELU), 2.0 * Mrows * F * C),
+            "ffn_down": (lambda: H.gemm(eng.ffn, Lw["w_f2"], eng.res, Lw["b_f2"], H.EPI_BF16), 2.0 * Mrows * C * F),
+        }
+        per, tot_ms, tot_fl = {}, 0.0, 0.0
+        with torch.no_grad():
+            for name, (fn, fl) in calls.items():
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for a, b in evs:
+                    a.record()
+                    fn()
+                    b.record()
+                torch.cuda.synchronize()
+                m = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+                per[name] = round(fl / m / 1e9, 1)
+                tot_ms += m
+                tot_fl += fl
+        roof2["block_linears"] = {"achieved": round(tot_fl / tot_ms / 1e9, 1), "frac": round(tot_fl / tot_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                  "ms": round(tot_ms, 4), "flop": tot_fl, "tflops_each": per}
 
     # ---- VAE decode of one video's latent (random-init full-width VAE), reported beside the loop
     vae_s = None
