@@ -117,7 +117,9 @@ def test_rmsnorm_rope_batched_and_offset(H):
 @pytest.mark.parametrize("M,N,K", [(1, 128, 64), (130, 256, 192), (300, 384, 1536), (257, 1536, 8960),
                                    (777, 256, 128), (1100, 512, 1536),
                                    # >= 512 tiles of 256 x 256: the ring-pipelined large-shape kernel
-                                   (8192, 4096, 128), (4999, 6656, 192), (16500, 2048, 320)])
+                                   (8192, 4096, 128), (4999, 6656, 192), (16500, 2048, 320),
+                                   # 27 x 19 = 513 tiles: the 8 XCD chunks of the tile walk are not all the same size
+                                   (6912, 4864, 256)])
 def test_gemm_epilogues(H, M, N, K):
     a = rb(syn.randn("g.a", (M, K), 3))
     w = rb(syn.uniform("g.w", (N, K), 1 / math.sqrt(K), 3))
