@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* halo = lds;                          // [HR*WR][LDV]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int TW = a.TW, TH = 128 / TW;
+    const int TW = a.TW, TH = 128 / TW;          // TW is a power of two (16 or 128)
+    const int tw_shift = __builtin_ctz(TW);
     const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
     int bid = blockIdx.x;
     const int tw_i = bid % tiles_w; bid /= tiles_w;
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
 
     // this lane's output voxel inside the tile (A-operand row) and its halo index per tap
     const int iv = wave * 32 + (lane & 31);
-    const int dh = iv / TW, dw = iv % TW;
+    const int dh = iv >> tw_shift, dw = iv & (TW - 1);
     const int kq = lane >> 5;                    // which half of the k pairs this lane feeds
 
     f32x16 acc[NB];
@@ -100,6 +101,30 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
 
     const int nchunk = (a.Cin + 31) >> 5;
     const long frame_elems = (long)a.H * a.W * a.Cin;
+    // Halo staging map.  Thread tid stages float4 (tid & 7) of voxels (tid >> 3) + 32 * it; which source pixel
+    // that is does not depend on (kt, chunk), so the division by the halo width is done once per workgroup.
+    // hpix: source pixel hs * W + ws; -1 outside the frame (zeros are staged); -2 beyond the halo (nothing is).
+    constexpr int HIT = 6;                       // covers halos of up to 192 voxels (stride-1 3x3: 10 x 18)
+    const int nvox = HR * WR;
+    const bool small_halo = nvox <= HIT * 32;
+    const int hv0 = tid >> 3, hj = tid & 7;
+    int hpix[HIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int v = hv0 + 32 * it;
+        const int hr = v / WR, wc_ = v - hr * WR;
+        const int hs = hs0 + hr, ws = ws0 + wc_;
+        hpix[it] = v >= nvox ? -2 : (hs >= 0 && hs < a.H && ws >= 0 && ws < a.W) ? hs * a.W + ws : -1;
+    }
+    const bool pre_split = SPLIT && a.ws != nullptr;
+    int wrow[NB];           // element offsets: the weight tensors hold far fewer than 2^31 values
+    bool wok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int co = n0 + hv0 + 32 * i;
+        wok[i] = co < a.Cout;
+        wrow[i] = pre_split ? co * nchunk * 64 + 8 * hj : co * a.Cin + 4 * hj;
+    }
     for (int kt = 0; kt < a.KT; ++kt) {
         const int ts = to * a.st + kt - a.pt;
         const float* fp; const float* rp;
@@ -109,6 +134,45 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
         if (fp == nullptr) continue;             // zero padding contributes nothing
         for (int cc = 0; cc < nchunk; ++cc) {
             __syncthreads();                      // previous users of halo / wt are done
+            if (small_halo) {
+                const int ci = cc * 32 + 4 * hj;
+                const bool cok = ci < a.Cin;
+                float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (a.gamma && cok) g = *reinterpret_cast<const float4*>(a.gamma + ci);
+                // two batches of three voxels: the loads of a batch are all issued before the first is used, and
+                // only 15 registers hold staged values (a sixth wave per CU is worth more than deeper batches)
+#pragma unroll
+                for (int b0 = 0; b0 < HIT; b0 += 3) {
+                    float4 val[3];
+                    float rn[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        rn[u] = 0.f;
+                        if (hpix[b0 + u] >= 0 && cok) {
+                            val[u] = *reinterpret_cast<const float4*>(fp + (long)hpix[b0 + u] * a.Cin + ci);
+                            if (a.gamma) rn[u] = rp[hpix[b0 + u]];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int it = b0 + u;
+                        if (hpix[it] == -2) continue;
+                        float4 x = val[u];
+                        if (hpix[it] >= 0 && cok) {
+                            if (a.gamma) {
+                                const float r = rn[u] * a.norm_scale;
+                                x.x = x.x * r * g.x; x.y = x.y * r * g.y;
+                                x.z = x.z * r * g.z; x.w = x.w * r * g.w;
+                            }
+                            if (a.silu) { x.x = silu_f(x.x); x.y = silu_f(x.y); x.z = silu_f(x.z); x.w = silu_f(x.w); }
+                        }
+                        float* dst = halo + (hv0 + 32 * it) * LDV;
+                        if (SPLIT) store_split4(reinterpret_cast<char*>(dst) + 8 * hj, x);
+                        else *reinterpret_cast<float4*>(dst + 4 * hj) = x;
+                    }
+                }
+            } else
             for (int idx = tid; idx < HR * WR * 8; idx += 256) {
                 const int v = idx >> 3, j = idx & 7;
                 const int hs = hs0 + v / WR, ws = ws0 + v % WR;
@@ -138,16 +202,14 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
             // With pre-split weights (a.ws: [tap][co][chunk][32 hi | 32 lo] bf16) a float4 is 16 raw
             // bytes of that 128-byte row and goes to LDS as is; otherwise it is four fp32 weights,
             // split while being written.
-            const bool pre_split = SPLIT && a.ws != nullptr;
+            // thread tid moves float4 (tid & 7) of weight rows (tid >> 3) + 32 * i: the per-thread part of the
+            // address is wrow[i] (set up once), the (kt, tap, chunk) part is the same for the whole workgroup
             auto w_ptr = [&](int tap_hw, int i) -> const float* {
-                const int idx = tid + i * 256, r = idx >> 3, j = idx & 7;
-                const int co = n0 + r, ci = cc * 32 + 4 * j;
-                if (co >= a.Cout) return nullptr;
-                if (pre_split)
-                    return reinterpret_cast<const float*>(
-                        a.ws + (((long)(kt * ntaps + tap_hw) * a.Cout + co) * nchunk + cc) * 64 + 8 * j);
-                if (ci >= a.Cin) return nullptr;
-                return a.w + ((long)(kt * ntaps + tap_hw) * a.Cout + co) * a.Cin + ci;
+                if (!wok[i]) return nullptr;
+                const long slice = (long)(kt * ntaps + tap_hw) * a.Cout;
+                if (pre_split) return reinterpret_cast<const float*>(a.ws + wrow[i] + (slice * nchunk + cc) * 64);
+                if (cc * 32 + 4 * hj >= a.Cin) return nullptr;
+                return a.w + wrow[i] + slice * a.Cin + cc * 32;
             };
             auto w_put = [&](float* buf, int i, const float4& val) {
                 const int idx = tid + i * 256, r = idx >> 3, j = idx & 7;
@@ -185,8 +247,11 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
                         // at +32*ks + 16*kq of the hi plane, the lo plane 64 bytes further
                         const char* ac = reinterpret_cast<const char*>(ap);
                         const char* bc = reinterpret_cast<const char*>(bp);
-                        const int k16 = (ksteps + 1) >> 1;
-                        for (int ks = 0; ks < k16; ++ks) {
+                        // both 16-wide k-steps always: a chunk's rows beyond Cin are staged as zeros, and a loop
+                        // with a run-time trip count here makes hipcc move all accumulators out of and back into
+                        // the AGPR file around it, once per tap (140 register moves beside 18 MFMAs)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
                             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ac + 32 * ks);
                             const bf16x8 al = *reinterpret_cast<const bf16x8*>(ac + 64 + 32 * ks);
 #pragma unroll
@@ -242,7 +307,7 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
-            const int ho = h0 + ov / TW, wo = w0 + ov % TW;
+            const int ho = h0 + (ov >> tw_shift), wo = w0 + (ov & (TW - 1));
             if (ho >= a.Ho || wo >= a.Wo) continue;
             const long o = (((long)frame * a.Ho + ho) * a.Wo + wo) * C_out_row + cch;
             float v = acc[nb][reg] + bv;
