@@ -270,6 +270,22 @@ def test_frames_resize_rejects_bad_input():
         H.frames_resize_normalize(torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device="cuda"), (2, 0, 8, 8), (4, 4), lut)
 
 
+def test_conv333_large_frame(H):
+    """A large frame (thousands of tiles, several grid rounds), ragged at both edges."""
+    cin, cout, T, Hh, Ww = 32, 96, 2, 250, 421
+    x = syn.randn("cvl.x", (cin, T, Hh, Ww), 1)
+    ctx = syn.randn("cvl.ctx", (cin, 2, Hh, Ww), 1)
+    w = syn.uniform("cvl.w", (cout, cin, 3, 3, 3), (27 * cin) ** -0.5, 1)
+    b = syn.randn("cvl.b", (cout,), 1, 0.1)
+    wk, k = prep_w(w)
+    ref = V.causal_conv(x, w, b, ctx)
+    c = cl(ctx)
+    y = H.vae_conv3d(cl(x), wk, b.cuda(), k, prev2=c[0], prev1=c[1], pad_t=2, pad_hw=1)
+    # 20 M outputs, each a sum of 864 products: the far tail of the summation-order differences of two
+    # fp32 sums reaches 2.5e-6 next to a zero crossing, hence twice the one-layer absolute tolerance
+    torch.testing.assert_close(cf(y), ref, rtol=RTOL, atol=2 * ATOL)
+
+
 @pytest.mark.skipif(EXACT, reason="this is the child process")
 def test_exact_fp32_path_in_fresh_process():
     """The same layer / encode / decode tests on the exact-fp32 matrix path at its tighter tolerance."""
