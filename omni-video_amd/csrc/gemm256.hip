@@ -51,6 +51,7 @@ constexpr int NPAIR = 2;                      // buffers
 enum Epi { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
@@ -269,7 +270,11 @@ gemm256_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ 
             for (int i = 0; i < 8; ++i) {
                 const int r = i * 16 + wave * 2 + (lane >> 5);
                 const uint4 v = *reinterpret_cast<const uint4*>(img + r * 512 + (((lane & 31) ^ (r & 15)) << 4));
-                if (row0 + hf * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)(hf * 128 + r) * ldo) = v;
+                // streaming store: the output is not read again by this kernel and would only push operand
+                // tiles out of L2 (1-2 % on the K = 1536 shapes)
+                if (row0 + hf * 128 + r < M)
+                    __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w},
+                                                reinterpret_cast<u32x4*>(ob + (long)(hf * 128 + r) * ldo));
             }
         }
     } else
