@@ -115,3 +115,49 @@ def test_phased_gemm_loop_keeps_its_order(tmp_path, src, kernel, mfma, count):
         loop, tail = loop_and_tail(body)
         assert loop == want_loop, (name, loop)
         assert tail == want_tail, (name, tail)
+
+
+def main_loop(body):
+    """Lines of the loop (label ... backward branch to it) that holds the most MFMAs; the shortest such loop."""
+    lines = body.split("\n")
+    labels = {}
+    for i, ln in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            labels[m.group(1)] = i
+    mfma = [0]
+    for ln in lines:
+        mfma.append(mfma[-1] + ("v_mfma" in ln))
+    best, key = (0, 0), (-1, 0)
+    for i, ln in enumerate(lines):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+        if m and labels.get(m.group(1), i) < i:
+            lo = labels[m.group(1)]
+            k = (mfma[i + 1] - mfma[lo], lo - i)
+            if k > key:
+                best, key = (lo, i), k
+    return lines[best[0]:best[1] + 1]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+@pytest.mark.parametrize("src,kernel,count", [("attn.hip", "attn_pipe_kernel", 2), ("attn.hip", "attn_i8_kernel", 2),
+                                              ("vae.hip", "conv3d_cl_kernel", 8)])
+def test_register_bound_loops_do_not_spill(tmp_path, src, kernel, count):
+    """The attention loop sits at the 256-register limit and the convolution at 168 (three waves per SIMD): a
+    change that tips either into scratch memory inside its loop costs far more than it can gain.  (Values
+    that are only needed after the loop may be parked in scratch across it; that is once per workgroup.)"""
+    text = listing(src, tmp_path)
+    ks = kernels(text, kernel)
+    assert len(ks) == count, sorted(ks)
+    for name, body in ks.items():
+        loop = main_loop(body)
+        assert sum("v_mfma" in ln for ln in loop) >= 4, (name, len(loop))
+        assert not any("scratch_" in ln for ln in loop), f"{name}: register spills inside the main loop"
+    if kernel == "attn_pipe_kernel":
+        w8 = next(b for n, b in ks.items() if "_w8" in n)
+        assert "scratch_" not in w8, "the self-attention kernel spills"
+    if kernel == "conv3d_cl_kernel":
+        # the split-bf16 kernel with 96 output channels per workgroup is the one the large layers run
+        meta = text[text.index("amdhsa.kernels"):]
+        m = re.search(r"\.name:\s+\S*conv3d_cl_kernelILi3ELb1E\S*.*?\.vgpr_count:\s+(\d+)", meta, re.S)
+        assert m and int(m.group(1)) <= 168, m and m.group(1)
