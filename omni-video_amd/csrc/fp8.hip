@@ -450,6 +450,8 @@ __device__ __forceinline__ void k_tile128(f32x16 (&acc)[2][4], char* smem, int b
 }
 
 // One 256 x 256 output tile: `bid` is the tile's position in the XCD-ordered walk.
+typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+
 template <int EPI>
 __device__ __forceinline__ void
 gemm_fp8p_tile(const uint8_t* __restrict__ A, long lda, const float* __restrict__ a_scale, float a_scale_all,
@@ -609,7 +611,9 @@ gemm_fp8p_tile(const uint8_t* __restrict__ A, long lda, const float* __restrict_
             for (int i = 0; i < 128 / RPI; ++i) {
                 const int r = i * RPI + rr;
                 const uint4 v = *reinterpret_cast<const uint4*>(img + r * ROWB + ((cc ^ (r & 15)) << 4));
-                if (row0 + mh * 128 + r < M) *reinterpret_cast<uint4*>(ob + (long)r * ldo * OB) = v;
+                if (row0 + mh * 128 + r < M)        // streaming store, as in the bf16 kernel
+                    __builtin_nontemporal_store((u32x4_nt){v.x, v.y, v.z, v.w},
+                                                reinterpret_cast<u32x4_nt*>(ob + (long)r * ldo * OB));
             }
         }
     }
