@@ -8,7 +8,9 @@
  * Conventions
  *   - every pointer is a borrowed DEVICE pointer (bf16 tensors are raw uint16_t bit
  *     patterns); nothing is retained after the call returns; no entry point allocates,
- *     frees or synchronises, so all of them may be captured into a HIP graph;
+ *     frees or synchronises, so all of them may be captured into a HIP graph (the one
+ *     exception, marked SET-UP at its declaration: the create / map / destroy functions of
+ *     the peer-mapped exchange buffers, ovd_peer_alloc ... ovd_peer_close);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *   - return value 0 = launched; non-zero = rejected before any launch, with the reason
  *     in ovd_last_error() (thread-local, valid until the next call on that thread);
@@ -377,6 +379,50 @@ int ovd_vae_from_channels_last(const float* in, float* out, const float* pre, co
 /* In-place softmax(scale * s[m,:]) over M rows of length N, fp32: the softmax of
  * F.scaled_dot_product_attention in AttentionBlock.forward (vae2_1.py:251-255). */
 int ovd_softmax_rows_f32(float* s, int M, int N, float scale, void* stream);
+
+/* ---- Sequence-parallel exchange through peer-mapped device memory --------------------------------
+ * The collectives of Ulysses attention without a collective library: every rank (one process per GPU)
+ * maps the exchange buffers of its peers once, and the exchange is plain kernels on the caller's
+ * stream - p concurrent reads, one per xGMI link of the full mesh - which can be captured into the HIP
+ * graph of the sampling step.  Replaces dist.all_to_all inside AllToAll / all_to_all
+ * (omnivideo/distributed/util.py:95-121, used by ulysses.py:41-43,55) together with the chunk /
+ * contiguous / cat copies around it (util.py:106-109), and the all-gather of the head output
+ * (util.py:124-130 via full_sequence_parallel.py:163).
+ *
+ * SET-UP functions (HOST; they allocate, free or map memory and are the exception to "no entry point
+ * allocates": explicit create / destroy, never called from a graph):
+ *   ovd_peer_alloc   device buffer that can be exported (zero-filled); fine_grained != 0 for the flag
+ *                    arrays (a store from another device must become visible to a kernel that is
+ *                    already running), 0 for payload;
+ *   ovd_peer_export  64-byte handle of a buffer from ovd_peer_alloc, to be sent to the peers by any
+ *                    host channel;  ovd_peer_open maps a peer's handle (in another process; a buffer of
+ *                    the same process is used through its own pointer);  ovd_peer_close / ovd_peer_free.
+ */
+int ovd_peer_alloc(void** ptr, int64_t bytes, int fine_grained);
+int ovd_peer_free(void* ptr);
+int ovd_peer_export(void* ptr, unsigned char handle[64]);
+int ovd_peer_open(const unsigned char handle[64], void** ptr);
+int ovd_peer_close(void* ptr);
+
+/* Barrier over the p ranks, on the stream.  my_flags: this rank's fine-grained array of p uint32 (zero at
+ * start); peer_flags: DEVICE array of p pointers, entry j = rank j's flag array as mapped here (entry
+ * `rank` = my_flags); state: 2 uint32 of this rank, zero at start ([0] epoch counter, [1] stays 0 unless a
+ * peer failed to arrive within timeout_s seconds: then 1 + that peer's rank, the kernel returns anyway and
+ * the caller must treat everything after as invalid).  When the kernel ends, every kernel that any rank
+ * launched on its stream before its own matching barrier has finished.  p <= 64. */
+int ovd_peer_barrier(uint32_t* my_flags, uint32_t* const* peer_flags, uint32_t* state, int p, int rank,
+                     double timeout_s, void* stream);
+
+/* recv[j] = chunk `rank` of rank j's send buffer, j < p: recv [p][chunk_bytes] local, peer_send a DEVICE
+ * array of p pointers to the ranks' send buffers [p][chunk_bytes] as mapped here.  chunk_bytes % 16 == 0.
+ * Call between two barriers: the one before makes the peers' send buffers complete, a later one must
+ * pass before a send buffer is rewritten. */
+int ovd_peer_all_to_all(void* recv, const void* const* peer_send, int64_t chunk_bytes, int p, int rank,
+                        void* stream);
+
+/* out[i] = sum over j < p of peer_src[j][i], i < n, fp32, added in rank order (identical bits on every
+ * rank); peer_src a DEVICE array of p pointers.  `out` must not be one of the published buffers. */
+int ovd_peer_sum_f32(float* out, const float* const* peer_src, int64_t n, int p, void* stream);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,14 @@ int ovd_impl_voxel_rnorm(const float*, float*, long, int, hipStream_t);
 int ovd_impl_to_cl(const float*, float*, const float*, const float*, const float*, int, int, long, hipStream_t);
 int ovd_impl_from_cl(const float*, float*, const float*, const float*, const float*, int, int, long, int, hipStream_t);
 int ovd_impl_softmax_rows(float*, int, int, float, hipStream_t);
+int ovd_impl_peer_alloc(void**, size_t, int);
+int ovd_impl_peer_free(void*);
+int ovd_impl_peer_export(void*, unsigned char*);
+int ovd_impl_peer_open(const unsigned char*, void**);
+int ovd_impl_peer_close(void*);
+int ovd_impl_peer_barrier(uint32_t*, uint32_t* const*, uint32_t*, int, int, double, hipStream_t);
+int ovd_impl_peer_all_to_all(void*, const void* const*, long, int, int, hipStream_t);
+int ovd_impl_peer_sum_f32(float*, const float* const*, long, int, hipStream_t);
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 #define NONNULL(p) OVD_REQUIRE((p) != nullptr, "%s: null pointer argument '%s'", __func__, #p)
@@ -384,6 +392,49 @@ int ovd_vae_from_channels_last(const float* in, float* out, const float* pre, co
 int ovd_softmax_rows_f32(float* s, int M, int N, float scale, void* stream) {
     NONNULL(s);
     return ovd_impl_softmax_rows(s, M, N, scale, ST(stream));
+}
+
+int ovd_peer_alloc(void** ptr, int64_t bytes, int fine_grained) {
+    NONNULL(ptr);
+    OVD_REQUIRE(bytes > 0, "peer_alloc: %lld bytes", (long long)bytes);
+    return ovd_impl_peer_alloc(ptr, (size_t)bytes, fine_grained);
+}
+
+int ovd_peer_free(void* ptr) {
+    NONNULL(ptr);
+    return ovd_impl_peer_free(ptr);
+}
+
+int ovd_peer_export(void* ptr, unsigned char handle[64]) {
+    NONNULL(ptr); NONNULL(handle);
+    return ovd_impl_peer_export(ptr, handle);
+}
+
+int ovd_peer_open(const unsigned char handle[64], void** ptr) {
+    NONNULL(handle); NONNULL(ptr);
+    return ovd_impl_peer_open(handle, ptr);
+}
+
+int ovd_peer_close(void* ptr) {
+    NONNULL(ptr);
+    return ovd_impl_peer_close(ptr);
+}
+
+int ovd_peer_barrier(uint32_t* my_flags, uint32_t* const* peer_flags, uint32_t* state, int p, int rank,
+                     double timeout_s, void* stream) {
+    NONNULL(my_flags); NONNULL(peer_flags); NONNULL(state);
+    return ovd_impl_peer_barrier(my_flags, peer_flags, state, p, rank, timeout_s, ST(stream));
+}
+
+int ovd_peer_all_to_all(void* recv, const void* const* peer_send, int64_t chunk_bytes, int p, int rank,
+                        void* stream) {
+    NONNULL(recv); NONNULL(peer_send);
+    return ovd_impl_peer_all_to_all(recv, peer_send, (long)chunk_bytes, p, rank, ST(stream));
+}
+
+int ovd_peer_sum_f32(float* out, const float* const* peer_src, int64_t n, int p, void* stream) {
+    NONNULL(out); NONNULL(peer_src);
+    return ovd_impl_peer_sum_f32(out, peer_src, (long)n, p, ST(stream));
 }
 
 }  // extern "C"

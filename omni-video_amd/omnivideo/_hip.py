@@ -58,6 +58,14 @@ SIGNATURES = {
     "ovd_vae_to_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _p],
     "ovd_vae_from_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
     "ovd_softmax_rows_f32": [_p, _i, _i, _f, _p],
+    "ovd_peer_alloc": [_p, _l, _i],
+    "ovd_peer_free": [_p],
+    "ovd_peer_export": [_p, _p],
+    "ovd_peer_open": [_p, _p],
+    "ovd_peer_close": [_p],
+    "ovd_peer_barrier": [_p, _p, _p, _i, _i, ctypes.c_double, _p],
+    "ovd_peer_all_to_all": [_p, _p, _l, _i, _i, _p],
+    "ovd_peer_sum_f32": [_p, _p, _l, _i, _p],
 }
 
 EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_RESID = 0, 1, 2, 3
@@ -623,3 +631,51 @@ def softmax_rows(s, scale):
     M, N = s.shape
     _call("ovd_softmax_rows_f32", _f32c(s), M, N, float(scale), _stream())
     return s
+
+
+# ---------------------------------------------------------------------------- peer-mapped exchange
+# (set-up calls take and return raw device addresses as Python ints; distributed/peer_mapped.py owns them)
+
+def peer_alloc(nbytes, fine_grained=False):
+    out = ctypes.c_void_p()
+    _call("ovd_peer_alloc", ctypes.byref(out), int(nbytes), 1 if fine_grained else 0)
+    return int(out.value)
+
+
+def peer_free(addr):
+    _call("ovd_peer_free", ctypes.c_void_p(addr))
+
+
+def peer_export(addr):
+    buf = (ctypes.c_ubyte * 64)()
+    _call("ovd_peer_export", ctypes.c_void_p(addr), buf)
+    return bytes(buf)
+
+
+def peer_open(handle):
+    if len(handle) != 64:
+        raise ValueError("an exported buffer handle is 64 bytes")
+    out = ctypes.c_void_p()
+    _call("ovd_peer_open", (ctypes.c_ubyte * 64).from_buffer_copy(handle), ctypes.byref(out))
+    return int(out.value)
+
+
+def peer_close(addr):
+    _call("ovd_peer_close", ctypes.c_void_p(addr))
+
+
+def peer_barrier(my_flags_addr, peer_flags_table, state, p, rank, timeout_s):
+    _call("ovd_peer_barrier", ctypes.c_void_p(my_flags_addr), _ptr(peer_flags_table, torch.int64),
+          _ptr(state, torch.int32), p, rank, float(timeout_s), _stream())
+
+
+def peer_all_to_all(recv, peer_send_table, chunk_bytes, p, rank):
+    if not recv.is_contiguous() or recv.numel() * recv.element_size() != p * chunk_bytes:
+        raise ValueError("peer_all_to_all: recv must be contiguous and hold p chunks")
+    _call("ovd_peer_all_to_all", _ptr(recv), _ptr(peer_send_table, torch.int64), int(chunk_bytes), p, rank, _stream())
+
+
+def peer_sum_f32(out, peer_src_table, p):
+    if not out.is_contiguous():
+        raise ValueError("peer_sum: out must be contiguous")
+    _call("ovd_peer_sum_f32", _ptr(out, F32), _ptr(peer_src_table, torch.int64), out.numel(), p, _stream())

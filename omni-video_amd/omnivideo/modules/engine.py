@@ -117,12 +117,27 @@ class TorchGroupComm:
         return torch.cat([p[:, :n] for p, n in zip(parts, rows)], dim=1)
 
 
-def make_group_comm(group=None):
-    """The communicator for a sequence-parallel process group: RCCL collectives on device tensors
-    ("nccl" backend), or the host-staged equivalent when the group's backend only moves host memory
-    (gloo: several ranks rehearsing on one GPU)."""
+def make_group_comm(group=None, kind=None):
+    """The communicator for a sequence-parallel process group.  kind (default: OVD_SP_COMM, else "auto"):
+      "rccl"  RCCL collectives on device tensors (the group's backend must be "nccl");
+      "host"  the host-staged equivalent for a backend that only moves host memory (gloo: several ranks
+              rehearsing on one GPU);
+      "auto"  "host" on a gloo group, else "rccl";
+      "peer"  peer-mapped device memory (distributed/peer_mapped.py): no collective library in the step,
+              one graph per step; the group's own backend is used for set-up and for the VAE decode."""
+    import os
     from ..distributed.host_staged import HostStagedComm, moves_host_memory_only
-    return HostStagedComm(group) if moves_host_memory_only(group) else TorchGroupComm(group)
+    kind = (kind or os.environ.get("OVD_SP_COMM") or "auto").lower()
+    if kind == "auto":
+        kind = "host" if moves_host_memory_only(group) else "rccl"
+    if kind == "peer":
+        from ..distributed.peer_mapped import PeerMappedComm
+        return PeerMappedComm(group)
+    if kind == "host":
+        return HostStagedComm(group)
+    if kind == "rccl":
+        return TorchGroupComm(group)
+    raise ValueError(f"OVD_SP_COMM / kind must be auto, rccl, host or peer, got {kind!r}")
 
 
 FP8_LINEARS = ("qkv", "o", "cq", "co", "f0", "f2")
@@ -246,9 +261,17 @@ class DiTEngine:
             self.k8_scale = e(nb, -(-seq_len // 64), N // sp, dt=F32)
         if sp > 1:
             Cs = C // sp
-            self.sp_send = e(3, nb, sp, S, Cs)        # q|k|v of my rows, split by destination head group
+            # what the peers receive from: ordinary memory for a collective library, exported memory for the
+            # peer-mapped communicator (its ranks read these two buffers in place)
+            shared = getattr(comm, "alloc", None)
+            if shared is not None:
+                for old in (getattr(self, "sp_send", None), getattr(self, "sp_o", None)):
+                    if old is not None and getattr(self, "comm", None) is comm:
+                        comm.free(old)
+            ex = (lambda *s: shared(s, BF16)) if shared is not None else e
+            self.sp_send = ex(3, nb, sp, S, Cs)       # q|k|v of my rows, split by destination head group
             self.sp_qkv = e(3, nb, seq_len, Cs)       # the full sequence for my head group (received in place)
-            self.sp_o = e(nb, seq_len, Cs)            # attention output, full sequence, my head group
+            self.sp_o = ex(nb, seq_len, Cs)           # attention output, full sequence, my head group
             self.sp_orecv = e(nb, sp, S, Cs)          # every head group's output for my rows
         self.grid, self.seq_len, self.nb, self.n_tok = tuple(grid), seq_len, nb, n_tok
         self.comm, self.sp, self.S, self.row0 = comm, sp, S, rank * S

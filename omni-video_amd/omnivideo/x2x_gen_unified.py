@@ -142,8 +142,9 @@ class DenoiseLoop:
             for b, c in saved:
                 b.copy_(c)
             torch.cuda.synchronize()
-            if self.engines[key].comm is not None:
-                # sequence parallel: graphs between the collectives, collectives eager
+            comm = self.engines[key].comm
+            if comm is not None and not getattr(comm, "capturable", False):
+                # sequence parallel over a collective library: graphs between the collectives, collectives eager
                 g = _SegmentedGraph(lambda: self._step(key), self.engines[key])
             else:
                 g = torch.cuda.CUDAGraph()
@@ -390,10 +391,13 @@ class OmniVideoX2XUnified:
                     c = m.build_mixed_context(1, context, ar_vision_input, visual_emb, self.special_tokens)[0]
                     u = m.build_mixed_context(1, context_null, ar_null, visual_emb, self.special_tokens)[0]
                     pairs[id(m)] = (c, u)
-            # with sequence parallelism the step replays as graphs between eager collectives
+            # with sequence parallelism the step replays as graphs between eager collectives (one graph with
+            # the peer-mapped communicator)
             loop = DenoiseLoop(models, lat, pairs, seq_len, sched, guide_scale, use_graph=self.use_graph,
                                comm=self.sp_comm)
             lat = loop.run()
+            if hasattr(self.sp_comm, "check"):
+                self.sp_comm.check()             # a peer-mapped barrier that gave up waiting invalidates the run
             if dist.is_initialized():
                 dist.barrier()
             is_decode_rank = (self.sp_rank == 0) if self.use_usp else (self.rank == 0)

@@ -23,8 +23,10 @@ def case_generate(outdir, rank, world):
     assert wm.forward.__func__.__name__ == "sp_dit_forward"
     assert wm.blocks[0].self_attn.forward.__func__.__name__ == "sp_attn_forward"
     assert wm.blocks[0].cross_attn.forward.__func__.__name__ == "sp_cross_attn_forward"
-    lat, video = case.run_generate(pipe, cfg)                 # graphs between eager collectives
-    from omnivideo.x2x_gen_unified import _SegmentedGraph
+    lat, video = case.run_generate(pipe, cfg)                 # graphs between eager collectives, or one graph
+    if os.environ.get("OVD_SP_COMM") == "peer":
+        from omnivideo.distributed.peer_mapped import PeerMappedComm
+        assert isinstance(pipe.sp_comm, PeerMappedComm) and pipe.sp_comm.barriers > 0
     pipe.use_graph = False
     lat_eager, _ = case.run_generate(pipe, cfg)               # every launch eager
     if lat is not None:
@@ -69,13 +71,68 @@ def case_attention(outdir, rank, world):
     torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
 
 
+def case_peer(outdir, rank, world):
+    """The peer-mapped communicator on its own: all-to-all, sum and barrier, eagerly and replayed from one
+    graph several times in a row, against values every rank can compute; then a barrier that one rank
+    never joins, which has to end with the status word set instead of hanging."""
+    from omnivideo.distributed.peer_mapped import PeerMappedComm
+    comm = PeerMappedComm(None, timeout_s=20)
+    dev = "cuda"
+    n = 3 * 1024 + 8                                   # elements per chunk (16-byte multiple, not a power of two)
+    send = comm.alloc((world, n), torch.bfloat16)
+    recv = torch.empty(world, n, dtype=torch.bfloat16, device=dev)
+    tot = torch.empty(4099, dtype=torch.float32, device=dev)          # odd length: scalar tail of the sum
+    val = lambda src, dst, it: (torch.arange(n, device=dev) % 251 + 7 * src + 3 * dst + it).to(torch.bfloat16)
+
+    def fill(it):
+        for j in range(world):
+            send[j].copy_(val(rank, j, it))
+        tot.copy_(torch.arange(4099, device=dev, dtype=torch.float32) * (rank + 1) + it)
+
+    def exchange():
+        comm.all_to_all(recv, send)
+        comm.all_reduce_sum(tot)
+
+    def verify(it):
+        for j in range(world):
+            assert torch.equal(recv[j], val(j, rank, it)), f"all_to_all chunk {j} iteration {it}"
+        want = sum(torch.arange(4099, device=dev, dtype=torch.float32) * (r + 1) + it for r in range(world))
+        assert torch.equal(tot, want), f"all_reduce_sum iteration {it}"
+
+    fill(0); exchange(); verify(0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        exchange()
+    for it in range(1, 5):
+        fill(it)
+        comm.barrier()                                 # peers have verified the previous round before send changes
+        g.replay()
+        verify(it)
+        comm.barrier()
+    comm.check()
+    torch.cuda.synchronize()
+    dist.barrier()
+    # a barrier that rank 0 alone enters: it must return after the timeout with the status word set
+    if rank == 0:
+        comm.timeout_s = 1.0
+        comm.barrier()
+        torch.cuda.synchronize()
+        try:
+            comm.check()
+        except RuntimeError as err:
+            assert "did not arrive" in str(err)
+        else:
+            raise AssertionError("a barrier nobody else joined reported success")
+    torch.save(dict(ok=True), os.path.join(outdir, f"rank{rank}.pt"))
+
+
 def main():
     which, outdir = sys.argv[1], sys.argv[2]
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="env://")
     rank, world = dist.get_rank(), dist.get_world_size()
     with torch.no_grad():
-        {"generate": case_generate, "attention": case_attention}[which](outdir, rank, world)
+        {"generate": case_generate, "attention": case_attention, "peer": case_peer}[which](outdir, rank, world)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")

@@ -26,9 +26,9 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def launch(script, args, nproc, timeout=300):
+def launch(script, args, nproc, timeout=300, **extra_env):
     port = free_port()
-    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, script)] + list(args)
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
@@ -36,8 +36,12 @@ def launch(script, args, nproc, timeout=300):
     assert res.stdout.count(" ok") == nproc, res.stdout[-2000:]
 
 
-def test_generate_with_usp_two_processes_equals_single_process(tmp_path):
-    launch("_sp_gpu_worker.py", ["generate", str(tmp_path)], 2)
+@pytest.mark.parametrize("sp_comm", ["auto", "peer"])
+def test_generate_with_usp_two_processes_equals_single_process(tmp_path, sp_comm):
+    """sp_comm "auto": the host-staged communicator (collectives eager between graphs); "peer": the
+    peer-mapped communicator - the two processes map each other's exchange buffers and every step,
+    exchanges included, replays as one graph."""
+    launch("_sp_gpu_worker.py", ["generate", str(tmp_path)], 2, OVD_SP_COMM=sp_comm)
     with torch.no_grad():
         pipe, cfg = case.build_pipeline(use_usp=False)
         lat, video = case.run_generate(pipe, cfg)
@@ -67,6 +71,10 @@ def test_sp_attention_forwards_two_processes_equal_unsharded(tmp_path):
         assert torch.equal(got["self"], want_self[:, r * s:(r + 1) * s]), f"sp_attn_forward rank {r}"
         assert torch.equal(got["cross"], want_cross[:, r * s:(r + 1) * s]), f"sp_cross_attn_forward rank {r}"
         assert torch.equal(got["ulysses"], got["ulysses_ref_rows"]), f"distributed_attention rank {r}"
+
+
+def test_peer_mapped_collectives_two_processes(tmp_path):
+    launch("_sp_gpu_worker.py", ["peer", str(tmp_path)], 2, timeout=120)
 
 
 def test_rccl_communicator_single_rank_group(tmp_path):
