@@ -135,8 +135,9 @@ _LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RA
 def companion_run(workload, n, extra, limit_s=600):
     """After the headline measurement, on rank 0 alone (the other ranks have exited and this process has
     released its buffers): the sequence-parallel configuration of the metric - one `workload` video over
-    all n GPUs, RCCL all-to-alls - as a separate job of n fresh ranks (this script again, self-launched),
-    bounded in time and isolated from the headline line: whatever happens to it, that line is printed."""
+    all n GPUs - as a separate job of n fresh ranks (this script again, self-launched; `extra` selects the
+    communicator), bounded in time and isolated from the headline line: whatever happens to it, that line
+    is printed."""
     import signal
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
@@ -159,7 +160,7 @@ def companion_run(workload, n, extra, limit_s=600):
         keep = ("value", "unit", "n_gpus", "ms_per_step", "scaling", "dtype", "context_encode_s_per_video",
                 "step_tflops", "roofline")
         res = {k: r.get(k) for k in keep}
-        res["config"] = {k: r["config"].get(k) for k in ("workload", "parallelism", "experts_resident",
+        res["config"] = {k: r["config"].get(k) for k in ("workload", "parallelism", "sp_comm", "experts_resident",
                                                           "timed_schedule_steps", "graph_replay")}
         res["wall_s"] = round(time.time() - t0, 1)
         return res
@@ -188,6 +189,11 @@ def main():
                          "the sequence-parallel configuration of the metric (cfg4: A14B 81f 720p over all N GPUs, "
                          "when 40 heads divide by N) as a separate bounded job and reports it under "
                          "'sequence_parallel_companion'; 'off' disables, a workload name selects another one")
+    ap.add_argument("--sp-comm", choices=["auto", "rccl", "host", "peer"], default="auto",
+                    help="communicator of the sequence-parallel group: rccl = all-to-alls of the collective library "
+                         "between graph segments; peer = peer-mapped device memory, the step is one graph "
+                         "(omnivideo/distributed/peer_mapped.py); auto = OVD_SP_COMM, else rccl (host-staged under "
+                         "--rehearse-on-one-gpu)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: every rank uses cuda:0 and the gloo backend, to exercise the "
                          "multi-rank control flow on a one-GPU box (numbers are meaningless)")
@@ -223,7 +229,7 @@ def main():
         if cfg["num_heads"] % world:
             raise SystemExit(f"sequence parallelism needs the {cfg['num_heads']} heads to divide by {world} ranks")
         from omnivideo.modules.engine import make_group_comm
-        comm = make_group_comm(None)          # RCCL; host-staged under --rehearse-on-one-gpu (gloo)
+        comm = make_group_comm(None, None if args.sp_comm == "auto" else args.sp_comm)
     K, W = args.steps, args.warmup
     if W + K > wl["steps"]:
         raise SystemExit(f"{W} warmup + {K} timed steps exceed the workload's {wl['steps']} sampling steps")
@@ -294,6 +300,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt, ctx_s = float(tt[0].item()), float(tt[1].item())
         assert torch.isfinite(lat.float()).all(), "latents went non-finite"
+        if hasattr(comm, "check"):
+            comm.check()
 
         # ---- roofline of the dominant kernel (self-attention): HIP events around each launch
         # of a second, eager pass of K steps on the same stream
@@ -411,6 +419,7 @@ def main():
             "config": {"workload": wl["desc"], "linear_precision": precision, "latent": list(wl["latent"]), "tokens": seq_len,
                        "context_len": wl["text_len"], "context_keys_read": cache.k_len, "sampling_steps": wl["steps"], "guide_scale": 3.0,
                        "parallelism": (f"sp{world}" if sp else f"dp{world}") if world > 1 else "single",
+                       "sp_comm": type(comm).__name__ if sp else None,
                        "scope": "per video: sampling_steps x the timed step (2 DiT forwards + CFG + UniPC) + the context "
                                 "encode (text embedding, cross-attention K/V of every layer and expert); VAE decode "
                                 "reported separately; graph capture is once per process and shape",
@@ -447,8 +456,15 @@ def main():
                 gc.collect()
                 torch.cuda.empty_cache()
                 time.sleep(5.0)
-                out["sequence_parallel_companion"] = companion_run(
-                    comp, world, ["--rehearse-on-one-gpu"] if args.rehearse_on_one_gpu else [])
+                # the same job twice within one time budget: over the collective library, then over
+                # peer-mapped memory (whole step as one graph)
+                extra = ["--rehearse-on-one-gpu"] if args.rehearse_on_one_gpu else []
+                t_comp = time.time()
+                out["sequence_parallel_companion"] = companion_run(comp, world, extra, limit_s=330)
+                left = 600 - (time.time() - t_comp)
+                out["sequence_parallel_companion_peer_mapped"] = (
+                    companion_run(comp, world, extra + ["--sp-comm", "peer"], limit_s=left) if left >= 150
+                    else {"skipped": f"{left:.0f} s of the companion budget left"})
             else:
                 out["sequence_parallel_companion"] = {"skipped": f"{comp}: heads do not divide by {world} ranks"}
         print(json.dumps(out))
