@@ -96,6 +96,26 @@ int ovd_qkv_norm_rope_bf16(const uint16_t* qkv, int64_t ld, const uint16_t* weig
 int ovd_gather_col_blocks_bf16(const uint16_t* src, uint16_t* dst, int64_t ldd, int64_t M, int nblk, int col_block,
                                void* stream);
 
+/* The two kernels above as sender and receiver of the sequence-parallel exchange itself, for ranks that
+ * have mapped each other's buffers (ovd_peer_* below): no all-to-all call and no copy pass remains.
+ * ovd_qkv_norm_rope_scatter_bf16: as ovd_qkv_norm_rope_bf16 with copy_v = 1, but column block b of every
+ * third goes to block_ptrs[b] (DEVICE array of C / col_block addresses, element offsets inside each as
+ * above with out_block_stride = 0): block_ptrs[j] = rank j's receive buffer [3][samples][p * rows][C/p] as
+ * mapped here, advanced to this rank's rows, makes the kernel that normalises and rotates q and k write
+ * them straight into every peer's attention operands over xGMI.
+ * ovd_gather_col_blocks_from_bf16: dst[m][b * col_block + c] = src_ptrs[b][m * col_block + c] (DEVICE array
+ * of nblk addresses); src_ptrs[j] = rank j's attention output for this rank's rows makes the head-gather
+ * read straight from the peers.  Blocks are walked starting at block `first` (pass own rank + 1 modulo
+ * nblk: the ranks then read from different peers at any time).
+ * Replace dist.all_to_all at omnivideo/distributed/util.py:95-121 as used by ulysses.py:41-43 and :55. */
+int ovd_qkv_norm_rope_scatter_bf16(const uint16_t* qkv, int64_t ld, const uint16_t* weight_q, const uint16_t* weight_k,
+                                   const float* rope, int rope_rows, uint16_t* const* block_ptrs, int64_t ldo,
+                                   int64_t out_part_stride, int col_block, int64_t out_sample_stride, int M, int C,
+                                   int head_dim, float eps, int rows_per_sample, int tok_offset, int n_rope, int gf,
+                                   int gh, int gw, void* stream);
+int ovd_gather_col_blocks_from_bf16(const uint16_t* const* src_ptrs, uint16_t* dst, int64_t ldd, int64_t M, int nblk,
+                                    int col_block, int first, void* stream);
+
 /* out = epilogue(A[M,K] * W[N,K]^T + bias[N]), bf16 operands, fp32 accumulation.
  * epilogue 0: bf16 out; 1: bf16 out of tanh-GELU(bf16-rounded pre-activation);
  * 2: fp32 out holding the bf16-rounded value; 3: fp32 in-place residual

@@ -19,9 +19,10 @@ int ovd_impl_ln_f32(float*, long, const bf16_t*, long, const float*, const float
                     const bf16_t*, float*, long, int, int, float, int, hipStream_t);
 int ovd_impl_rmsnorm_rope(const bf16_t*, long, const bf16_t*, const float*, int, bf16_t*, long, int, int, int, float,
                           int, int, int, int, int, int, hipStream_t);
-int ovd_impl_qkv_norm_rope(const bf16_t*, long, const bf16_t*, const bf16_t*, const float*, int, bf16_t*, long, long, int,
-                           long, long, int, int, int, int, float, int, int, int, int, int, int, hipStream_t);
-int ovd_impl_gather_col_blocks(const bf16_t*, bf16_t*, long, long, int, int, hipStream_t);
+int ovd_impl_qkv_norm_rope(const bf16_t*, long, const bf16_t*, const bf16_t*, const float*, int, bf16_t*, bf16_t* const*,
+                           long, long, int, long, long, int, int, int, int, float, int, int, int, int, int, int,
+                           hipStream_t);
+int ovd_impl_gather_col_blocks(const bf16_t*, const bf16_t* const*, bf16_t*, long, long, int, int, int, hipStream_t);
 int ovd_impl_gemm_bf16(const bf16_t*, long, const bf16_t*, long, const bf16_t*, void*, long, const float*, int, int,
                        int, int, hipStream_t);
 int ovd_impl_attn_fwd(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, long, long,
@@ -117,15 +118,33 @@ int ovd_qkv_norm_rope_bf16(const uint16_t* qkv, int64_t ld, const uint16_t* weig
                            int gw, void* stream) {
     NONNULL(qkv); NONNULL(weight_q); NONNULL(weight_k); NONNULL(rope); NONNULL(out);
     OVD_REQUIRE(M >= 0 && C > 0, "qkv_norm_rope: bad shape M=%d C=%d", M, C);
-    return ovd_impl_qkv_norm_rope(qkv, ld, weight_q, weight_k, rope, rope_rows, out, ldo, out_part_stride, col_block,
-                                  out_block_stride, out_sample_stride, copy_v, M, C, head_dim, eps, rows_per_sample,
-                                  tok_offset, n_rope, gf, gh, gw, ST(stream));
+    return ovd_impl_qkv_norm_rope(qkv, ld, weight_q, weight_k, rope, rope_rows, out, nullptr, ldo, out_part_stride,
+                                  col_block, out_block_stride, out_sample_stride, copy_v, M, C, head_dim, eps,
+                                  rows_per_sample, tok_offset, n_rope, gf, gh, gw, ST(stream));
+}
+
+int ovd_qkv_norm_rope_scatter_bf16(const uint16_t* qkv, int64_t ld, const uint16_t* weight_q, const uint16_t* weight_k,
+                                   const float* rope, int rope_rows, uint16_t* const* block_ptrs, int64_t ldo,
+                                   int64_t out_part_stride, int col_block, int64_t out_sample_stride, int M, int C,
+                                   int head_dim, float eps, int rows_per_sample, int tok_offset, int n_rope, int gf,
+                                   int gh, int gw, void* stream) {
+    NONNULL(qkv); NONNULL(weight_q); NONNULL(weight_k); NONNULL(rope); NONNULL(block_ptrs);
+    OVD_REQUIRE(M >= 0 && C > 0, "qkv_norm_rope: bad shape M=%d C=%d", M, C);
+    return ovd_impl_qkv_norm_rope(qkv, ld, weight_q, weight_k, rope, rope_rows, nullptr, block_ptrs, ldo,
+                                  out_part_stride, col_block, 0, out_sample_stride, 1, M, C, head_dim, eps,
+                                  rows_per_sample, tok_offset, n_rope, gf, gh, gw, ST(stream));
 }
 
 int ovd_gather_col_blocks_bf16(const uint16_t* src, uint16_t* dst, int64_t ldd, int64_t M, int nblk, int col_block,
                                void* stream) {
     NONNULL(src); NONNULL(dst);
-    return ovd_impl_gather_col_blocks(src, dst, ldd, M, nblk, col_block, ST(stream));
+    return ovd_impl_gather_col_blocks(src, nullptr, dst, ldd, M, nblk, col_block, 0, ST(stream));
+}
+
+int ovd_gather_col_blocks_from_bf16(const uint16_t* const* src_ptrs, uint16_t* dst, int64_t ldd, int64_t M, int nblk,
+                                    int col_block, int first, void* stream) {
+    NONNULL(src_ptrs); NONNULL(dst);
+    return ovd_impl_gather_col_blocks(nullptr, src_ptrs, dst, ldd, M, nblk, col_block, first, ST(stream));
 }
 
 int ovd_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias, void* out,

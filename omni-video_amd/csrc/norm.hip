@@ -116,8 +116,13 @@ int ovd_impl_ln_f32(float* x, long ldx, const bf16_t* res, long ldr, const float
 // cb8 16-byte chunks that sit out_block_stride elements apart, at row offset
 // (row / rows_per_sample) * out_sample_stride + (row % rows_per_sample) * ldo: in place this is the input
 // layout itself; for sequence parallelism it is the all-to-all send image [part][sample][dest rank][row][C/p].
+// With block_ptrs (a device array, one base address per column block) block b goes to block_ptrs[b] instead
+// of out + b * out_block_stride: the column blocks then land in different buffers - the receive buffers of
+// the sequence-parallel peers, mapped into this process, so that the kernel that produces q and k is also
+// the sender.
 struct RnParts {
     const bf16_t* weight[2];
+    bf16_t* const* block_ptrs;
     long in_part_stride, out_part_stride, out_block_stride, out_sample_stride;
     int cb8;
 };
@@ -141,10 +146,11 @@ __global__ void __launch_bounds__(256) rmsnorm_rope_kernel(const bf16_t* __restr
     auto chunk = [&](int i) -> int { return (i * WPR + (int)((threadIdx.x >> 6) & (WPR - 1))) * 64 + (int)(threadIdx.x & 63); };
     const uint4* src = reinterpret_cast<const uint4*>(in + (long)row * ldi + part * pp.in_part_stride);
     const int srow = row % rows_per_sample;
-    bf16_t* orow = out + part * pp.out_part_stride + (long)(row / rows_per_sample) * pp.out_sample_stride + (long)srow * ldo;
+    const long orow = part * pp.out_part_stride + (long)(row / rows_per_sample) * pp.out_sample_stride + (long)srow * ldo;
     auto ochunk = [&](int c) -> uint4* {      // where 16-byte chunk c of this row goes
         const int blk = pp.cb8 == nchunk ? 0 : c / pp.cb8;
-        return reinterpret_cast<uint4*>(orow + (long)blk * pp.out_block_stride + (long)(c - blk * pp.cb8) * 8);
+        bf16_t* base = pp.block_ptrs ? pp.block_ptrs[blk] : out + (long)blk * pp.out_block_stride;
+        return reinterpret_cast<uint4*>(base + orow + (long)(c - blk * pp.cb8) * 8);
     };
     uint4 raw[NCH], wq[NCH];
 #pragma unroll
@@ -265,6 +271,7 @@ int ovd_impl_rmsnorm_rope(const bf16_t* in, long ldi, const bf16_t* weight, cons
                           int tok_offset, int n_rope, int gf, int gh, int gw, hipStream_t st) {
     RnParts pp;
     pp.weight[0] = pp.weight[1] = weight;
+    pp.block_ptrs = nullptr;
     pp.in_part_stride = pp.out_part_stride = pp.out_block_stride = 0;
     pp.out_sample_stride = (long)rows_per_sample * ldo;       // plain rows: row m at m * ldo
     pp.cb8 = C / 8;
@@ -274,10 +281,13 @@ int ovd_impl_rmsnorm_rope(const bf16_t* in, long ldi, const bf16_t* weight, cons
 
 // q | k | v thirds of fused projection rows [M, 3C] in one launch: RMSNorm (own weight each) + RoPE on q and k;
 // v is copied when copy_v (its destination differs from its source).  Output layout: struct RnParts.
+// out == nullptr: the column blocks go to block_ptrs[b] (a device array of C / col_block addresses).
 int ovd_impl_qkv_norm_rope(const bf16_t* qkv, long ld, const bf16_t* wq, const bf16_t* wk, const float* rope,
-                           int rope_rows, bf16_t* out, long ldo, long out_part_stride, int col_block,
-                           long out_block_stride, long out_sample_stride, int copy_v, int M, int C, int D, float eps,
-                           int rows_per_sample, int tok_offset, int n_rope, int gf, int gh, int gw, hipStream_t st) {
+                           int rope_rows, bf16_t* out, bf16_t* const* block_ptrs, long ldo, long out_part_stride,
+                           int col_block, long out_block_stride, long out_sample_stride, int copy_v, int M, int C,
+                           int D, float eps, int rows_per_sample, int tok_offset, int n_rope, int gf, int gh, int gw,
+                           hipStream_t st) {
+    OVD_REQUIRE((out != nullptr) != (block_ptrs != nullptr), "qkv_norm_rope: exactly one of out / block_ptrs");
     OVD_REQUIRE(col_block > 0 && col_block % 8 == 0 && C % col_block == 0,
                 "qkv_norm_rope: col_block=%d must be a multiple of 8 dividing C=%d", col_block, C);
     OVD_REQUIRE(ld >= 3L * C, "qkv_norm_rope: input rows shorter than 3*C");
@@ -286,6 +296,7 @@ int ovd_impl_qkv_norm_rope(const bf16_t* qkv, long ld, const bf16_t* wq, const b
     RnParts pp;
     pp.weight[0] = wq;
     pp.weight[1] = wk;
+    pp.block_ptrs = block_ptrs;
     pp.in_part_stride = C;
     pp.out_part_stride = out_part_stride;
     pp.out_block_stride = out_block_stride;
@@ -296,29 +307,39 @@ int ovd_impl_qkv_norm_rope(const bf16_t* qkv, long ld, const bf16_t* wq, const b
 }
 
 // dst[m][b * cb + c] = src[b][m][c]: column blocks that arrive one after another (the attention output of
-// each head group after the sequence-parallel all-to-all) back into rows.  16 bytes per lane.
-__global__ void __launch_bounds__(256) gather_col_blocks_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
-                                                                long M, int nblk, int cb8, long ldd8) {
-    const long total = M * nblk * cb8;
+// each head group after the sequence-parallel all-to-all) back into rows.  16 bytes per lane.  With src_ptrs
+// (device array) block b is read from src_ptrs[b][m][c] instead: the blocks then sit in different buffers -
+// the attention outputs of the sequence-parallel peers, mapped into this process - and the gather is also
+// the receive.  The blocks are walked starting at block `first`, so that ranks read from different peers.
+__global__ void __launch_bounds__(256) gather_col_blocks_kernel(const uint4* __restrict__ src,
+                                                                const uint4* const* __restrict__ src_ptrs,
+                                                                uint4* __restrict__ dst, long M, int nblk, int cb8,
+                                                                long ldd8, int first) {
+    const long per = M * cb8;
+    const long total = per * nblk;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % cb8);
         const long t = i / cb8;
         const long m = t % M;
-        const int b = (int)(t / M);
-        dst[m * ldd8 + (long)b * cb8 + c] = src[i];
+        int b = (int)(t / M) + first;
+        b = b >= nblk ? b - nblk : b;
+        const uint4* s = src_ptrs ? src_ptrs[b] : src + b * per;
+        dst[m * ldd8 + (long)b * cb8 + c] = s[m * cb8 + c];
     }
 }
 
-int ovd_impl_gather_col_blocks(const bf16_t* src, bf16_t* dst, long ldd, long M, int nblk, int col_block,
-                               hipStream_t st) {
+int ovd_impl_gather_col_blocks(const bf16_t* src, const bf16_t* const* src_ptrs, bf16_t* dst, long ldd, long M,
+                               int nblk, int col_block, int first, hipStream_t st) {
+    OVD_REQUIRE((src != nullptr) != (src_ptrs != nullptr), "gather_col_blocks: exactly one of src / src_ptrs");
     OVD_REQUIRE(col_block > 0 && col_block % 8 == 0 && ldd % 8 == 0 && ldd >= (long)nblk * col_block,
                 "gather_col_blocks: col_block=%d and the destination stride must be multiples of 8", col_block);
-    OVD_REQUIRE(M >= 0 && nblk > 0, "gather_col_blocks: bad shape");
+    OVD_REQUIRE(M >= 0 && nblk > 0 && first >= 0 && first < nblk, "gather_col_blocks: bad shape");
     if (M == 0) return 0;
     const long total = M * nblk * (col_block / 8);
     const int blocks = (int)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
     hipLaunchKernelGGL(gather_col_blocks_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(src),
-                       reinterpret_cast<uint4*>(dst), M, nblk, col_block / 8, ldd / 8);
+                       reinterpret_cast<const uint4* const*>(src_ptrs), reinterpret_cast<uint4*>(dst), M, nblk,
+                       col_block / 8, ldd / 8, first);
     OVD_CHECK_LAUNCH("gather_col_blocks");
     return 0;
 }

@@ -21,6 +21,8 @@ SIGNATURES = {
     "ovd_rmsnorm_rope_bf16": [_p, _l, _p, _p, _i, _p, _l, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p],
     "ovd_qkv_norm_rope_bf16": [_p, _l, _p, _p, _p, _i, _p, _l, _l, _i, _l, _l, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p],
     "ovd_gather_col_blocks_bf16": [_p, _p, _l, _l, _i, _i, _p],
+    "ovd_qkv_norm_rope_scatter_bf16": [_p, _l, _p, _p, _p, _i, _p, _l, _l, _i, _l, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p],
+    "ovd_gather_col_blocks_from_bf16": [_p, _p, _l, _l, _i, _i, _i, _p],
     "ovd_gemm_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _p],
     "ovd_flash_attn_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p],
     "ovd_flash_attn_tail_fwd_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _p],
@@ -220,6 +222,34 @@ def qkv_norm_rope(qkv, wq, wk, head_dim, eps, rope, rows_per_sample, tok_offset,
     _call("ovd_qkv_norm_rope_bf16", _ptr(qkv, BF16), ld, _ptr(wq, BF16), _ptr(wk, BF16), _ptr(rope, F32), rope.shape[1],
           _ptr(out, BF16), ldo, part, cb, blk, samp, copy_v, M, C, head_dim, float(eps), rows_per_sample, tok_offset,
           n_rope, grid[0], grid[1], grid[2], _stream())
+
+
+def qkv_norm_rope_scatter(qkv, wq, wk, head_dim, eps, rope, rows_per_sample, tok_offset, n_rope, grid, block_ptrs,
+                          total_rows):
+    """qkv_norm_rope whose column block j (C / p columns: the heads of rank j) goes to the buffer at
+    block_ptrs[j] (int64 device tensor of p addresses): each a [3, samples, total_rows, C/p] bf16 receive
+    buffer already advanced to this rank's first row.  The caller owns the validity of the addresses."""
+    M, C3, ld = _rows(qkv)
+    C = C3 // 3
+    p = block_ptrs.numel()
+    if wq.numel() != C or wk.numel() != C or C % p or M % rows_per_sample:
+        raise ValueError("qkv_norm_rope_scatter: shape mismatch")
+    cb, ns = C // p, M // rows_per_sample
+    _call("ovd_qkv_norm_rope_scatter_bf16", _ptr(qkv, BF16), ld, _ptr(wq, BF16), _ptr(wk, BF16), _ptr(rope, F32),
+          rope.shape[1], _ptr(block_ptrs, torch.int64), cb, ns * total_rows * cb, cb, total_rows * cb, M, C, head_dim,
+          float(eps), rows_per_sample, tok_offset, n_rope, grid[0], grid[1], grid[2], _stream())
+
+
+def gather_col_blocks_from(src_ptrs, dst, first=0):
+    """dst [M, nblk * cb]: dst[m, b*cb + c] = (buffer at src_ptrs[b])[m, c]; src_ptrs an int64 device tensor of
+    nblk addresses of contiguous bf16 [M, cb] blocks.  The caller owns the validity of the addresses."""
+    nblk = src_ptrs.numel()
+    M, Cd, ldd = _rows(dst)
+    if Cd % nblk:
+        raise ValueError("gather_col_blocks_from: the destination width does not split into the blocks")
+    _call("ovd_gather_col_blocks_from_bf16", _ptr(src_ptrs, torch.int64), _ptr(dst, BF16), ldd, M, nblk, Cd // nblk,
+          int(first) % nblk, _stream())
+    return dst
 
 
 def gather_col_blocks(src, dst):

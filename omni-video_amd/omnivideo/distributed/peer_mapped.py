@@ -14,6 +14,10 @@ exchanges included, is captured as ONE HIP graph (`capturable`), where the RCCL 
 Interface = `engine.TorchGroupComm`'s, plus
   alloc(shape, dtype)   COLLECTIVE: a tensor in exported memory.  A tensor passed as `send` to
                         `all_to_all` must come from here (peers read it in place);
+  table(t, offset)      the addresses of such a tensor on every rank, for kernels that address the peers
+                        themselves: with `direct` (default) the engine's RMSNorm+RoPE kernel writes q, k, v
+                        straight into every peer's attention operands and its head-gather kernel reads the
+                        attention outputs straight from the peers - two barriers per layer and no copy pass;
   barrier()             stream-ordered barrier over the group;
   check()               raises if a barrier ever timed out (host synchronisation; call it at the end of
                         a run).
@@ -49,8 +53,11 @@ class _Region:
 class PeerMappedComm:
     capturable = True          # every method issues stream work only: a step may be captured as one graph
 
-    def __init__(self, group=None, timeout_s=None, base=None):
+    def __init__(self, group=None, timeout_s=None, base=None, direct=None):
         from .host_staged import HostStagedComm, moves_host_memory_only
+        # direct: the engine's kernels write to / read from the peers themselves (two barriers per layer, no
+        # copy pass); otherwise every exchange is barrier + all_to_all (OVD_PEER_DIRECT=0)
+        self.direct = (os.environ.get("OVD_PEER_DIRECT", "1") != "0") if direct is None else bool(direct)
         self.group = group
         self.size = dist.get_world_size(group=group)
         self.rank = dist.get_rank(group=group)
@@ -113,6 +120,12 @@ class PeerMappedComm:
             if reg.base <= a and a + t.numel() * t.element_size() <= reg.base + reg.nbytes:
                 return reg, a - reg.base
         raise ValueError("all_to_all: `send` must be a tensor from this communicator's alloc() (peers read it in place)")
+
+    def table(self, t, elem_offset=0):
+        """Device array (int64) of the addresses of element `elem_offset` of tensor `t` (from alloc()) in every
+        rank's copy: what a kernel needs to write into, or read from, the peers directly."""
+        reg, off = self._region_of(t)
+        return self._table(reg, off + int(elem_offset) * t.element_size())
 
     def alloc(self, shape, dtype):
         """COLLECTIVE.  A zero-filled tensor in exported memory."""

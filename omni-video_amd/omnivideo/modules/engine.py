@@ -264,15 +264,26 @@ class DiTEngine:
             # what the peers receive from: ordinary memory for a collective library, exported memory for the
             # peer-mapped communicator (its ranks read these two buffers in place)
             shared = getattr(comm, "alloc", None)
-            if shared is not None:
-                for old in (getattr(self, "sp_send", None), getattr(self, "sp_o", None)):
-                    if old is not None and getattr(self, "comm", None) is comm:
-                        comm.free(old)
+            self.sp_direct = shared is not None and bool(getattr(comm, "direct", False))
+            if shared is not None and getattr(self, "comm", None) is comm:
+                for old in getattr(self, "_sp_shared", ()):
+                    comm.free(old)
             ex = (lambda *s: shared(s, BF16)) if shared is not None else e
-            self.sp_send = ex(3, nb, sp, S, Cs)       # q|k|v of my rows, split by destination head group
-            self.sp_qkv = e(3, nb, seq_len, Cs)       # the full sequence for my head group (received in place)
-            self.sp_o = ex(nb, seq_len, Cs)           # attention output, full sequence, my head group
-            self.sp_orecv = e(nb, sp, S, Cs)          # every head group's output for my rows
+            if self.sp_direct:
+                # the peers write q|k|v into sp_qkv and read sp_o themselves: no send image, no receive copy
+                self.sp_qkv = ex(3, nb, seq_len, Cs)
+                self.sp_o = ex(nb, seq_len, Cs)
+                self.sp_send = self.sp_orecv = None
+                self._sp_shared = (self.sp_qkv, self.sp_o)
+                row0_el = rank * S * Cs
+                self._sp_qkv_tab = comm.table(self.sp_qkv, row0_el)
+                self._sp_o_tabs = [comm.table(self.sp_o, b * seq_len * Cs + row0_el) for b in range(nb)]
+            else:
+                self.sp_send = ex(3, nb, sp, S, Cs)   # q|k|v of my rows, split by destination head group
+                self.sp_qkv = e(3, nb, seq_len, Cs)   # the full sequence for my head group (received in place)
+                self.sp_o = ex(nb, seq_len, Cs)       # attention output, full sequence, my head group
+                self.sp_orecv = e(nb, sp, S, Cs)      # every head group's output for my rows
+                self._sp_shared = (self.sp_send, self.sp_o) if shared is not None else ()
         self.grid, self.seq_len, self.nb, self.n_tok = tuple(grid), seq_len, nb, n_tok
         self.comm, self.sp, self.S, self.row0 = comm, sp, S, rank * S
         self._shape = key
@@ -328,6 +339,19 @@ class DiTEngine:
         or unpacking copies (the reference chunks, copies and concatenates around each of its four
         all-to-alls, util.py:106-109)."""
         N, D, nb, S, sp = self.num_heads, self.head_dim, self.nb, self.S, self.sp
+        if self.sp_direct:
+            # Peer-mapped exchange: q, k, v go from the kernel that produces them into every peer's attention
+            # operands; after the barrier all of mine have arrived.  The second barrier says every rank's
+            # attention is done: the outputs may be read from the peers (and sp_qkv may be written again).
+            H.qkv_norm_rope_scatter(self.qkv.view(nb * S, -1), L["nq"], L["nk"], D, self.eps, self.rope, S, self.row0,
+                                    self.n_tok, self.grid, self._sp_qkv_tab, self.seq_len)
+            self.comm.barrier()
+            q4, k4, v4 = (self.sp_qkv[i].unflatten(2, (N // sp, D)) for i in range(3))
+            self._self_attention(q4, k4, v4, self.sp_o.unflatten(2, (N // sp, D)))
+            self.comm.barrier()
+            for b in range(nb):
+                H.gather_col_blocks_from(self._sp_o_tabs[b], self.att[b], first=self.comm.rank + 1)
+            return
         H.qkv_norm_rope(self.qkv.view(nb * S, -1), L["nq"], L["nk"], D, self.eps, self.rope, S, self.row0,
                         self.n_tok, self.grid, send=self.sp_send)
         for part in range(3):

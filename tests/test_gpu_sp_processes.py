@@ -36,12 +36,16 @@ def launch(script, args, nproc, timeout=300, **extra_env):
     assert res.stdout.count(" ok") == nproc, res.stdout[-2000:]
 
 
-@pytest.mark.parametrize("sp_comm", ["auto", "peer"])
+@pytest.mark.parametrize("sp_comm", ["auto", "peer", "peer-pull"])
 def test_generate_with_usp_two_processes_equals_single_process(tmp_path, sp_comm):
     """sp_comm "auto": the host-staged communicator (collectives eager between graphs); "peer": the
-    peer-mapped communicator - the two processes map each other's exchange buffers and every step,
-    exchanges included, replays as one graph."""
-    launch("_sp_gpu_worker.py", ["generate", str(tmp_path)], 2, OVD_SP_COMM=sp_comm)
+    peer-mapped communicator - the two processes map each other's exchange buffers, the RMSNorm+RoPE kernel
+    writes q, k, v into the peer's attention operands, the head-gather reads the peer's attention output,
+    and every step, exchanges included, replays as one graph; "peer-pull": the same communicator with
+    every exchange as barrier + all-to-all copy kernel."""
+    env = dict(OVD_SP_COMM="peer", OVD_PEER_DIRECT="0" if sp_comm == "peer-pull" else "1") if sp_comm != "auto" \
+        else dict(OVD_SP_COMM="auto")
+    launch("_sp_gpu_worker.py", ["generate", str(tmp_path)], 2, **env)
     with torch.no_grad():
         pipe, cfg = case.build_pipeline(use_usp=False)
         lat, video = case.run_generate(pipe, cfg)
