@@ -126,13 +126,65 @@ def case_peer(outdir, rank, world):
     torch.save(dict(ok=True), os.path.join(outdir, f"rank{rank}.pt"))
 
 
+def engine_case(precision, comm=None, replays=0):
+    """One DiT forward of a 4-head tiny model over seq_len 80 (8 padding rows), optionally sharded over
+    `comm` and replayed from a graph; the inputs of tests/test_gpu_sequence_parallel.py."""
+    from omnivideo.modules.engine import DiTEngine
+    from omnivideo.modules.unified_model import UnifiedWanWithMixedConditionModel
+    from omnivideo.utils import synthetic as syn
+    BF16 = torch.bfloat16
+    cfg = syn.dit_config("tiny", dim=512, num_heads=4, ffn_dim=512)
+    m = UnifiedWanWithMixedConditionModel(wan_config=dict(cfg), vlm_in_dim=cfg["vlm_in_dim"],
+                                          use_visual_context_adapter=True,
+                                          visual_context_adapter_patch_size=cfg["visual_patch_size"],
+                                          max_context_len=cfg["text_len"], eps=cfg["eps"], skip_init=True)
+    m.load_state_dict(syn.make_unified_state_dict(cfg, 0), strict=True)
+    wm = m.to(BF16).cuda().eval().wan_model
+    lat = syn.randn("in.lat", (16, 3, 8, 12), 1).cuda().to(BF16)
+    ctxs = [syn.randn("in.text", (10, cfg["text_dim"]), 1).cuda().to(BF16),
+            syn.randn("in.text_null", (6, cfg["text_dim"]), 1).cuda().to(BF16)]
+    ts = torch.tensor([640.0], dtype=torch.float64, device="cuda")
+    eng = DiTEngine(wm, precision=precision)
+    eng.plan((3, 4, 6), 80, 2, comm=comm)
+    cache = eng.encode_context(ctxs, wm.text_len)
+    out = torch.empty(2, 16, 3, 8, 12, device="cuda")
+    eng.forward(lat, ts, cache, out)
+    torch.cuda.synchronize()
+    first = out.clone()
+    if replays:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            eng.forward(lat, ts, cache, out)
+        for _ in range(replays):
+            out.fill_(float("nan"))
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, first), "graph replay of the sharded forward differs from the eager one"
+    return first
+
+
+def case_peer_engine(outdir, rank, world):
+    """The sharded engine forward over `world` processes with the peer-mapped communicator (kernels write to
+    and read from the peers), eager and as one replayed graph, bf16 and reduced precision."""
+    from omnivideo.distributed.peer_mapped import PeerMappedComm
+    res = {}
+    for precision in ("bf16", "fp8"):
+        for direct in (True, False):
+            comm = PeerMappedComm(None, timeout_s=20, direct=direct)
+            res[f"{precision}_{'direct' if direct else 'pull'}"] = engine_case(precision, comm, replays=3).cpu()
+            comm.check()
+            comm.close()
+    torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
+
+
 def main():
     which, outdir = sys.argv[1], sys.argv[2]
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="env://")
     rank, world = dist.get_rank(), dist.get_world_size()
     with torch.no_grad():
-        {"generate": case_generate, "attention": case_attention, "peer": case_peer}[which](outdir, rank, world)
+        {"generate": case_generate, "attention": case_attention, "peer": case_peer,
+         "peer_engine": case_peer_engine}[which](outdir, rank, world)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")
