@@ -126,28 +126,35 @@ def case_peer(outdir, rank, world):
     torch.save(dict(ok=True), os.path.join(outdir, f"rank{rank}.pt"))
 
 
-def engine_case(precision, comm=None, replays=0):
-    """One DiT forward of a 4-head tiny model over seq_len 80 (8 padding rows), optionally sharded over
-    `comm` and replayed from a graph; the inputs of tests/test_gpu_sequence_parallel.py."""
+def engine_case(precision, comm=None, replays=0, shape="tiny4"):
+    """One DiT forward, optionally sharded over `comm` and replayed from a graph.  shape "tiny4": a 4-head
+    tiny model over seq_len 80 (8 padding rows; the inputs of tests/test_gpu_sequence_parallel.py); "a14b":
+    one layer of the A14B width (C = 5120, 40 heads, FFN 13 824) on the full 81-frame 720p grid, 75 600
+    tokens (the inputs of tests/test_gpu_fullsize_a14b.py)."""
     from omnivideo.modules.engine import DiTEngine
     from omnivideo.modules.unified_model import UnifiedWanWithMixedConditionModel
     from omnivideo.utils import synthetic as syn
     BF16 = torch.bfloat16
-    cfg = syn.dit_config("tiny", dim=512, num_heads=4, ffn_dim=512)
+    if shape == "a14b":
+        cfg = syn.dit_config("A14B", num_layers=1, text_len=512)
+        lat_shape, grid, seq_len = (16, 21, 90, 160), (21, 45, 80), 75600
+    else:
+        cfg = syn.dit_config("tiny", dim=512, num_heads=4, ffn_dim=512)
+        lat_shape, grid, seq_len = (16, 3, 8, 12), (3, 4, 6), 80
     m = UnifiedWanWithMixedConditionModel(wan_config=dict(cfg), vlm_in_dim=cfg["vlm_in_dim"],
                                           use_visual_context_adapter=True,
                                           visual_context_adapter_patch_size=cfg["visual_patch_size"],
                                           max_context_len=cfg["text_len"], eps=cfg["eps"], skip_init=True)
     m.load_state_dict(syn.make_unified_state_dict(cfg, 0), strict=True)
     wm = m.to(BF16).cuda().eval().wan_model
-    lat = syn.randn("in.lat", (16, 3, 8, 12), 1).cuda().to(BF16)
+    lat = syn.randn("in.lat", lat_shape, 1).cuda().to(BF16)
     ctxs = [syn.randn("in.text", (10, cfg["text_dim"]), 1).cuda().to(BF16),
             syn.randn("in.text_null", (6, cfg["text_dim"]), 1).cuda().to(BF16)]
     ts = torch.tensor([640.0], dtype=torch.float64, device="cuda")
     eng = DiTEngine(wm, precision=precision)
-    eng.plan((3, 4, 6), 80, 2, comm=comm)
+    eng.plan(grid, seq_len, 2, comm=comm)
     cache = eng.encode_context(ctxs, wm.text_len)
-    out = torch.empty(2, 16, 3, 8, 12, device="cuda")
+    out = torch.empty(2, *lat_shape, device="cuda")
     eng.forward(lat, ts, cache, out)
     torch.cuda.synchronize()
     first = out.clone()
@@ -177,6 +184,18 @@ def case_peer_engine(outdir, rank, world):
     torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
 
 
+def case_peer_a14b(outdir, rank, world):
+    """One A14B-width layer on the 75 600-token grid over `world` ranks (8: the per-rank shapes of the
+    81-frame 720p workload - 9 450 rows, 5 heads, exchange buffers of 0.6 GB addressed on 8 peers)."""
+    from omnivideo.distributed.peer_mapped import PeerMappedComm
+    comm = PeerMappedComm(None, timeout_s=60)
+    out = engine_case("bf16", comm, replays=1, shape="a14b")
+    comm.check()
+    if rank in (0, world - 1):                    # every rank holds the full output; two of them are compared
+        torch.save(dict(out=out.cpu()), os.path.join(outdir, f"rank{rank}.pt"))
+    comm.close()
+
+
 def main():
     which, outdir = sys.argv[1], sys.argv[2]
     torch.cuda.set_device(0)
@@ -184,7 +203,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     with torch.no_grad():
         {"generate": case_generate, "attention": case_attention, "peer": case_peer,
-         "peer_engine": case_peer_engine}[which](outdir, rank, world)
+         "peer_engine": case_peer_engine, "peer_a14b": case_peer_a14b}[which](outdir, rank, world)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")
