@@ -111,6 +111,50 @@ def cpu_baseline(cfg, wl, threads):
             "seconds_measured": round(sum(times), 2)}
 
 
+def measure_attention_traffic(B, L, N, limit_s=75):
+    """HBM-side bytes of one self-attention launch at this shape, counted now: two `rocprofv3 --pmc` passes
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass) over a child process that runs only that launch
+    (tools/bench_kernels.py attnbal).  On gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so it
+    is doubled; WRITE_SIZE is exact; both are reported in KiB.  Returns (bytes, description) or raises."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        raise RuntimeError("rocprofv3 not found")
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("this run is itself being profiled")
+    kib = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            env = dict(os.environ, TMPDIR="/tmp", OVD_BENCH_ATTN_SHAPE=f"{B},{L},{N}")
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "bench_kernels.py"), "attnbal"]
+            proc = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                proc.wait(timeout=limit_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                raise RuntimeError(f"{counter} pass killed after {limit_s} s")
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if proc.returncode != 0 or not files:
+                raise RuntimeError(f"{counter} pass: exit status {proc.returncode}, {len(files)} counter files")
+            vals = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
+                    if r["Counter_Name"] == counter and "attn_pipe_kernel" in r["Kernel_Name"]]
+            if not vals:
+                raise RuntimeError(f"{counter} pass: no attention launch in the counter file")
+            kib[counter] = sum(vals) / len(vals)
+    nbytes = int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024)
+    return nbytes, (f"measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch in a child "
+                    f"process (B{B} L{L} N{N}; FETCH_SIZE {kib['FETCH_SIZE']:.0f} KiB doubled for gfx950, WRITE_SIZE "
+                    f"{kib['WRITE_SIZE']:.0f} KiB; the tail-merge kernel's ~24 MB not included)")
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N fresh ranks under torch.distributed.run
     (this process has not touched the GPU and never does), pass their output through and exit with
@@ -179,6 +223,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE decode leg")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 counter passes that measure the attention launch's HBM-side bytes")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--parallel", choices=["auto", "dp", "sp"], default="auto",
                     help="with --gpus N > 1: dp = one video per GPU (no data-path collective); sp = one video "
@@ -323,11 +369,16 @@ def main():
             # HBM-side bytes per launch cannot be counted from here: they come from separate
             # rocprofv3 --pmc passes over the same kernel at the cfg2 shape, kept under profiles/
             traffic, tsrc = None, None
-            for name in ("r2_attn_self_pmc_traffic.json", "r1_attn_self_pmc_traffic.json"):
+            if world == 1 and not args.no_traffic and eng.attention == "bf16":
+                try:
+                    traffic, tsrc = measure_attention_traffic(2, L, cfg["num_heads"])
+                except Exception as err:          # noqa: BLE001 - the counters are an extra, the line must survive
+                    tsrc = f"live counter passes failed ({type(err).__name__}: {err}); "
+            for name in (() if traffic is not None else ("r2_attn_self_pmc_traffic.json", "r1_attn_self_pmc_traffic.json")):
                 tpath = os.path.join(ROOT, "profiles", name)
                 if args.workload in ("cfg2", "cfg3") and os.path.exists(tpath):
                     traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-                    tsrc = f"offline rocprofv3 --pmc passes at this shape, profiles/{name} (not measured by this run)"
+                    tsrc = (tsrc or "") + f"offline rocprofv3 --pmc passes at this shape, profiles/{name} (not measured by this run)"
                     break
             int8_attn = eng.attention == "int8"
             # int8 Q K^T runs at twice the bf16 rate, P V at the bf16 rate, half of the FLOPs each:

@@ -172,8 +172,9 @@ if __name__ == "__main__":
     if "attn8" in args.what:
         attn_qk8(2, 20280, 12)
         attn_qk8(2, 75600, 5)
-    if "attnbal" in args.what:      # the cfg2 self-attention launch alone (for counter passes)
-        attn(2, 20280, 20280, 12, balance=True)
+    if "attnbal" in args.what:      # one self-attention shape alone (for counter passes); default: cfg2's
+        B_, L_, N_ = (int(v) for v in os.environ.get("OVD_BENCH_ATTN_SHAPE", "2,20280,12").split(","))
+        attn(B_, L_, L_, N_, balance=True)
     if "xattn131" in args.what:     # cross-attention as the cfg2 model runs it: 131 keys read, fused K|V cache
         for kl in (131, 512, 1024, 2048):
             attn(2, 20280, 6144, 12, k_len=kl, strided_q=True, fused_kv=True)
