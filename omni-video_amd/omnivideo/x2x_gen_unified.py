@@ -237,7 +237,8 @@ class OmniVideoX2XUnified:
             self.sp_size = get_sequence_parallel_size()
             self.sp_rank = get_rank(self.sp_group)
             from .modules.engine import make_group_comm
-            self.sp_comm = make_group_comm(self.sp_group) if self.sp_size > 1 else None
+            with torch.cuda.device(self.device):      # a peer-mapped communicator allocates its buffers here
+                self.sp_comm = make_group_comm(self.sp_group) if self.sp_size > 1 else None
         else:
             self.sp_group, self.sp_size, self.sp_rank, self.sp_comm = None, 1, 0, None
 
