@@ -189,10 +189,12 @@ def case_peer_a14b(outdir, rank, world):
     81-frame 720p workload - 9 450 rows, 5 heads, exchange buffers of 0.6 GB addressed on 8 peers)."""
     from omnivideo.distributed.peer_mapped import PeerMappedComm
     comm = PeerMappedComm(None, timeout_s=60)
-    out = engine_case("bf16", comm, replays=1, shape="a14b")
-    comm.check()
+    res = {}
+    for precision in ("bf16", "fp8"):             # fp8: e4m3 linear layers + int8 Q K^T, the 81-frame V2V workload's mode
+        res[precision] = engine_case(precision, comm, replays=1, shape="a14b").cpu()
+        comm.check()
     if rank in (0, world - 1):                    # every rank holds the full output; two of them are compared
-        torch.save(dict(out=out.cpu()), os.path.join(outdir, f"rank{rank}.pt"))
+        torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
     comm.close()
 
 

@@ -100,14 +100,15 @@ def test_peer_mapped_a14b_geometry_eight_processes_equals_unsharded(tmp_path):
     """The sequence-parallel configuration of the 81-frame 720p workload at its real per-rank shapes: one
     layer of the A14B width over 8 ranks (8 processes sharing this GPU), q | k | v written into the eight
     peers' attention operands, outputs read back from them, replayed as a graph: bitwise equal to the
-    unsharded forward."""
+    unsharded forward, in bf16 and in the reduced-precision mode."""
     import _sp_gpu_worker as W
     launch("_sp_gpu_worker.py", ["peer_a14b", str(tmp_path)], 8, timeout=280)
-    with torch.no_grad():
-        want = W.engine_case("bf16", shape="a14b").cpu()
-    for r in (0, 7):
-        got = torch.load(tmp_path / f"rank{r}.pt", weights_only=True)["out"]
-        assert torch.equal(got, want), f"rank {r}: max diff {(got - want).abs().max().item()}"
+    for precision in ("bf16", "fp8"):
+        with torch.no_grad():
+            want = W.engine_case(precision, shape="a14b").cpu()
+        for r in (0, 7):
+            got = torch.load(tmp_path / f"rank{r}.pt", weights_only=True)[precision]
+            assert torch.equal(got, want), f"{precision} rank {r}: max diff {(got - want).abs().max().item()}"
 
 
 def test_rccl_communicator_single_rank_group(tmp_path):
