@@ -424,12 +424,15 @@ int ovd_peer_export(void* ptr, unsigned char handle[64]);
 int ovd_peer_open(const unsigned char handle[64], void** ptr);
 int ovd_peer_close(void* ptr);
 
-/* Barrier over the p ranks, on the stream.  my_flags: this rank's fine-grained array of p uint32 (zero at
- * start); peer_flags: DEVICE array of p pointers, entry j = rank j's flag array as mapped here (entry
- * `rank` = my_flags); state: 2 uint32 of this rank, zero at start ([0] epoch counter, [1] stays 0 unless a
- * peer failed to arrive within timeout_s seconds: then 1 + that peer's rank, the kernel returns anyway and
- * the caller must treat everything after as invalid).  When the kernel ends, every kernel that any rank
- * launched on its stream before its own matching barrier has finished.  p <= 64. */
+/* Barrier over the p ranks, on the stream.  my_flags: this rank's fine-grained array of 128 uint32 (zero at
+ * start: [j] = epoch reached by rank j, [64 + j] = rank j has given up on a barrier); peer_flags: DEVICE array
+ * of p pointers, entry j = rank j's flag array as mapped here (entry `rank` = my_flags); state: 2 uint32 of
+ * this rank, zero at start ([0] epoch counter; [1] stays 0 unless the group has failed: 1 + j = rank j did not
+ * arrive within timeout_s seconds at a barrier of this rank, 65 + j = rank j reported such a failure of its
+ * own).  A failure is told to every peer, so one barrier later state[1] is set on every rank; the kernel
+ * returns in any case and the caller must treat everything after as invalid.  When the kernel ends without
+ * failure, every kernel that any rank launched on its stream before its own matching barrier has finished.
+ * p <= 64. */
 int ovd_peer_barrier(uint32_t* my_flags, uint32_t* const* peer_flags, uint32_t* state, int p, int rank,
                      double timeout_s, void* stream);
 

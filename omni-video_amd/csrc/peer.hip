@@ -68,29 +68,47 @@ int ovd_impl_peer_close(void* ptr) {
 }
 
 // ------------------------------------------------------------------------------ barrier
-// One lane per peer.  state[0] = epoch of the last barrier this rank passed, state[1] = 0 or 1 + the
-// first peer that did not arrive in time (sticky).  Epochs only grow and a rank can be at most one
-// barrier ahead of a peer, so "flag - epoch >= 0" in wrapping arithmetic is the arrival test.
+// One lane per peer.  A rank's flag array holds 2 x 64 words: [j] = the epoch peer j has reached, [64 + j] =
+// non-zero once peer j has given up on a barrier.  state[0] = epoch of the last barrier this rank passed,
+// state[1] = 0, or 1 + j when peer j did not arrive in time here, or 65 + j when peer j reported that one of
+// ITS barriers failed (sticky, first cause wins).  Epochs only grow and a rank can be at most one barrier
+// ahead of a peer, so "flag - epoch >= 0" in wrapping arithmetic is the arrival test.
+// A rank whose wait times out goes on unsynchronised, so everything the group computes from then on is
+// invalid - on every rank, not only on this one.  It therefore marks itself as failed in every peer's array
+// (now and again in every later barrier), and a rank that finds a peer's mark stops waiting for it and records
+// the failure too: within one barrier of the first time-out every rank's status word is set.
 __global__ void __launch_bounds__(64) peer_barrier_kernel(uint32_t* my_flags, uint32_t* const* peer_flags,
                                                           uint32_t* state, int p, int rank, long long timeout_ticks) {
-    __shared__ uint32_t e_sh;
+    __shared__ uint32_t e_sh, bad_sh;
     const int j = threadIdx.x;
-    if (j == 0) e_sh = state[0] + 1u;
+    if (j == 0) {
+        e_sh = state[0] + 1u;
+        bad_sh = state[1];
+    }
     __syncthreads();
     const uint32_t e = e_sh;
+    const bool failed_before = bad_sh != 0u;
     if (j < p) {
+        if (failed_before)
+            __hip_atomic_store(&peer_flags[j][64 + rank], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence_system();
         __hip_atomic_store(&peer_flags[j][rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const long long t0 = wall_clock64();
         while ((int32_t)(__hip_atomic_load(&my_flags[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+            if (__hip_atomic_load(&my_flags[64 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
             if (wall_clock64() - t0 > timeout_ticks) {
                 atomicCAS(&state[1], 0u, (uint32_t)(j + 1));
                 break;
             }
             __builtin_amdgcn_s_sleep(16);
         }
+        // a peer that failed earlier may be ahead of this rank: its epochs are all there, its data are not
+        if (__hip_atomic_load(&my_flags[64 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+            atomicCAS(&state[1], 0u, (uint32_t)(65 + j));
     }
     __syncthreads();
+    if (j < p && !failed_before && __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        __hip_atomic_store(&peer_flags[j][64 + rank], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (j == 0) state[0] = e;
 }
 

@@ -19,8 +19,8 @@ Interface = `engine.TorchGroupComm`'s, plus
                         straight into every peer's attention operands and its head-gather kernel reads the
                         attention outputs straight from the peers - two barriers per layer and no copy pass;
   barrier()             stream-ordered barrier over the group;
-  check()               raises if a barrier ever timed out (host synchronisation; call it at the end of
-                        a run).
+  check()               COLLECTIVE: raises on every rank if a barrier of any rank ever timed out (host
+                        synchronisation; call it at the end of a run).
 Ordering rule for callers: a `send` tensor may be rewritten once this rank has issued one more
 collective of this communicator after the `all_to_all` that read it (the engine's layer loop does:
 q/k/v are rewritten after the output exchange, the output after the next layer's q/k/v exchange).
@@ -53,8 +53,18 @@ class _Region:
 class PeerMappedComm:
     capturable = True          # every method issues stream work only: a step may be captured as one graph
 
-    def __init__(self, group=None, timeout_s=None, base=None, direct=None):
+    def __init__(self, group=None, timeout_s=None, base=None, direct=None, payload=None):
+        """payload: "default" = exchange buffers in ordinary (coarse-grained) device memory: what a kernel wrote
+        reaches the peers when the kernel ends (the release at the end of every kernel writes its dirty L2 lines
+        back) and a reading kernel sees it because it starts after its own barrier kernel has ended (the acquire
+        at the start of every kernel invalidates the non-coherent cache levels); "fine" = fine-grained memory,
+        which the hardware keeps coherent across devices at every access (slower on the owning GPU: its own
+        accesses bypass the L2 for such lines).  Default: OVD_PEER_PAYLOAD, else "default"."""
         from .host_staged import HostStagedComm, moves_host_memory_only
+        payload = (payload or os.environ.get("OVD_PEER_PAYLOAD") or "default").lower()
+        if payload not in ("default", "fine"):
+            raise ValueError(f"OVD_PEER_PAYLOAD / payload must be 'default' or 'fine', got {payload!r}")
+        self.payload = payload
         # direct: the engine's kernels write to / read from the peers themselves (two barriers per layer, no
         # copy pass); otherwise every exchange is barrier + all_to_all (OVD_PEER_DIRECT=0)
         self.direct = (os.environ.get("OVD_PEER_DIRECT", "1") != "0") if direct is None else bool(direct)
@@ -69,17 +79,19 @@ class PeerMappedComm:
         self.base = base
         self.timeout_s = float(os.environ.get("OVD_PEER_TIMEOUT_S", "30") if timeout_s is None else timeout_s)
         self._regions, self._tables = [], {}
-        self._flags = self._new_region(256, fine_grained=True)
+        self._flags = self._new_region(512, fine_grained=True)   # 64 epoch words + 64 failure marks
         self._flag_table = self._table(self._flags, 0)
         self._state = torch.zeros(2, dtype=torch.int32, device="cuda")
-        self._stage = None
+        self._stage = None         # the newest (largest) staging region of all_reduce_sum; older ones stay mapped
         self.barriers = 0          # barrier launches issued (captured ones count once)
 
     # ------------------------------------------------------------------ exported memory
-    def _new_region(self, nbytes, fine_grained=False):
+    def _new_region(self, nbytes, fine_grained=None):
         """COLLECTIVE.  Allocates `nbytes` of exportable device memory on every rank and maps every
         peer's buffer here."""
         nbytes = -(-int(nbytes) // 256) * 256
+        if fine_grained is None:
+            fine_grained = self.payload == "fine"
         base = H.peer_alloc(nbytes, fine_grained)
         mine = (os.getpid(), socket.gethostname(), base, nbytes, H.peer_export(base))
         infos = [None] * self.size
@@ -181,8 +193,8 @@ class PeerMappedComm:
         if self._stage is None or self._stage.nbytes < nbytes:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("first all_reduce_sum of this size under graph capture: run the step once eagerly")
-            if self._stage is not None:
-                self.free(self._stage.bytes)
+            # a smaller staging region stays allocated and mapped until close(): graphs captured earlier hold
+            # its addresses on this rank and on the peers
             self._stage = self._new_region(nbytes)
         tab = self._table(self._stage, 0)
         self._stage.bytes[:nbytes].view(F32).copy_(t.view(-1))
@@ -190,12 +202,31 @@ class PeerMappedComm:
         H.peer_sum_f32(t, tab, self.size)
         self.barrier()                       # every rank has read them: the staging buffer is free again
 
-    def check(self):
-        """Raises if any barrier of this rank gave up waiting (host synchronisation)."""
-        who = int(self._state[1].item())
-        if who:
-            raise RuntimeError(f"peer-mapped barrier: rank {who - 1} did not arrive within {self.timeout_s} s; "
-                               "results after that point are invalid")
+    def status(self):
+        """This rank's barrier status word (host synchronisation): 0, or 1 + j (rank j did not arrive in time at
+        one of this rank's barriers), or 65 + j (rank j reported a failed barrier of its own)."""
+        return int(self._state[1].item())
+
+    def check(self, collective=True):
+        """COLLECTIVE (host synchronisation; call it on every rank at the end of a run).  Raises on EVERY rank
+        of the group if any rank's barrier gave up waiting: a rank that timed out went on unsynchronised, so the
+        results of all ranks are invalid from that point, and a rank that raised alone would leave the others
+        blocked in their next collective.  collective=False looks at this rank's status word only."""
+        who = self.status()
+        worst = who
+        if collective and self.size > 1:
+            from .host_staged import moves_host_memory_only
+            t = torch.tensor([who], dtype=torch.int32, device="cpu" if moves_host_memory_only(self.group) else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            worst = int(t.item())
+        if worst:
+            if 1 <= who <= 64:
+                mine = f"rank {who - 1} did not arrive at a barrier of rank {self.rank} within {self.timeout_s} s"
+            elif who > 64:
+                mine = f"rank {who - 65} reported a barrier that gave up waiting"
+            else:
+                mine = "another rank of the group reported a barrier that gave up waiting"
+            raise RuntimeError(f"peer-mapped barrier failed: {mine}; results after that point are invalid on every rank")
 
     # ------------------------------------------------------------------ eager exchanges of the VAE decode
     def exchange_rows(self, up, down):

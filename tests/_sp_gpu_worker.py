@@ -74,7 +74,7 @@ def case_attention(outdir, rank, world):
 def case_peer(outdir, rank, world):
     """The peer-mapped communicator on its own: all-to-all, sum and barrier, eagerly and replayed from one
     graph several times in a row, against values every rank can compute; then a barrier that one rank
-    never joins, which has to end with the status word set instead of hanging."""
+    joins too late, which has to end with the status word set on every rank instead of hanging."""
     from omnivideo.distributed.peer_mapped import PeerMappedComm
     comm = PeerMappedComm(None, timeout_s=20)
     dev = "cuda"
@@ -112,17 +112,28 @@ def case_peer(outdir, rank, world):
     comm.check()
     torch.cuda.synchronize()
     dist.barrier()
-    # a barrier that rank 0 alone enters: it must return after the timeout with the status word set
-    if rank == 0:
-        comm.timeout_s = 1.0
-        comm.barrier()
-        torch.cuda.synchronize()
-        try:
-            comm.check()
-        except RuntimeError as err:
-            assert "did not arrive" in str(err)
-        else:
-            raise AssertionError("a barrier nobody else joined reported success")
+    # A barrier that the last rank joins too late: the ranks that gave up waiting (1 s) mark themselves as
+    # failed in every peer's flag array and go on; the late rank finds their epochs already there, passes - and
+    # must find the marks as well.  check() then has to raise on EVERY rank (a rank that raised alone would
+    # leave the others blocked in their next collective).
+    import time
+    comm.timeout_s = 1.0
+    if rank == world - 1:
+        time.sleep(3.0)
+    comm.barrier()
+    torch.cuda.synchronize()
+    own = comm.status()
+    assert own != 0, "the failed barrier left this rank's status word clear"
+    assert (own == world if rank < world - 1 else own > 64), f"rank {rank}: status word {own}"
+    dist.barrier()
+    try:
+        comm.check()
+    except RuntimeError as err:
+        assert "barrier failed" in str(err) and "every rank" in str(err), str(err)
+    else:
+        raise AssertionError(f"rank {rank}: check() passed although a barrier of the group timed out")
+    comm.barrier()                                     # later barriers return at once instead of waiting
+    torch.cuda.synchronize()
     torch.save(dict(ok=True), os.path.join(outdir, f"rank{rank}.pt"))
 
 
