@@ -25,6 +25,10 @@ static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C-ABI passes IPC handles as 
 // ------------------------------------------------------------------------------ set-up (host side)
 int ovd_impl_peer_alloc(void** ptr, size_t bytes, int fine_grained) {
     OVD_REQUIRE(ptr != nullptr && bytes > 0, "peer_alloc: bad arguments");
+    // hipIpcOpenMemHandle (ROCm 7.2, dmabuf IPC) never returns for an allocation whose size has bit 31 set in its
+    // low 32 bits - 2 GiB hangs, 2 GiB - 4 KiB and 4 GiB map at once (probed with tools/ipc_size_probe.py) - so
+    // such a size is rounded up to the next multiple of 4 GiB.
+    if ((bytes & 0xFFFFFFFFull) >= 0x80000000ull) bytes = (bytes + 0xFFFFFFFFull) & ~(size_t)0xFFFFFFFFull;
     void* p = nullptr;
     const hipError_t e = hipExtMallocWithFlags(&p, bytes, fine_grained ? hipDeviceMallocFinegrained : hipDeviceMallocDefault);
     if (e != hipSuccess) OVD_FAIL("peer_alloc: %zu bytes (%s): %s", bytes, fine_grained ? "fine-grained" : "default",

@@ -143,6 +143,40 @@ def make_group_comm(group=None, kind=None):
 FP8_LINEARS = ("qkv", "o", "cq", "co", "f0", "f2")
 
 
+def planned_bytes(cfg, grid, seq_len, nb, text_len, sp=1, precision="bf16", attention=None, attn_workspace=0):
+    """Device bytes one expert needs on one rank before anything is allocated: {"parameters": the module's
+    bf16 parameters, "engine_copies": the fused / quantised weight copies DiTEngine.__init__ makes,
+    "context_cache": encode_context's per-layer K/V for nb branches (+ its two transient embedding buffers),
+    "workspaces": what plan() allocates for this shape (attn_workspace = H.flash_attn_workspace_bytes of the
+    shape, which depends on the device), "total"}.  cfg: the WanModel configuration (dim, ffn_dim, num_heads,
+    num_layers, text_dim, freq_dim, in_dim, out_dim, patch_size)."""
+    C, F, N, nl = cfg["dim"], cfg["ffn_dim"], cfg["num_heads"], cfg["num_layers"]
+    attention = attention or ("int8" if precision == "fp8" else "bf16")
+    kpatch = cfg.get("in_dim", 16) * math.prod(cfg.get("patch_size", (1, 2, 2)))
+    per_layer = 8 * C * C + 2 * C * F + 8 * C + C + F + 2 * C + 4 * C + 6 * C    # linears, biases, norms, modulation
+    outside = (kpatch * C + C) + (cfg["text_dim"] * C + C * C + 2 * C) + (cfg.get("freq_dim", 256) * C + C * C + 2 * C) \
+        + (6 * C * C + 6 * C) + (C * cfg.get("out_dim", 16) * math.prod(cfg.get("patch_size", (1, 2, 2))) + 2 * C + 64)
+    params = 2 * (nl * per_layer + outside)
+    if precision == "fp8":
+        copies = nl * (2 * (2 * C * C + 2 * C) + (6 * C * C + 2 * C * F) + 4 * (8 * C + 2 * F))
+    else:
+        copies = nl * 2 * (5 * C * C + 5 * C)
+    ctx = nl * nb * text_len * 2 * C * 2 + 2 * nb * text_len * C * 2 + nb * text_len * cfg["text_dim"] * 2
+    S = seq_len // sp
+    M = nb * S
+    n_tok = grid[0] * grid[1] * grid[2]
+    ws = M * C * 4 + M * 3 * C * 2 + M * C * 2 + M * C * 2 + M * C * 4 + n_tok * kpatch * 2     # x, qkv, att, res, y, rows
+    ws += (2 * M * C + 8 * M + M * F) if precision == "fp8" else (M * C * 2 + M * F * 2)        # h / att / ffn operands
+    ws += nl * 6 * C * 4 + attn_workspace
+    if attention == "int8":
+        ws += 2 * nb * seq_len * (C // sp) + 4 * nb * seq_len * (N // sp) + 4 * nb * -(-seq_len // 64) * (N // sp)
+    if sp > 1:
+        ws += (3 + 1 + 3 + 1) * nb * seq_len * (C // sp) * 2      # send image / operands / output / returned output
+    return {"parameters": params, "engine_copies": copies, "context_cache": ctx, "workspaces": ws,
+            "total": params + copies + ctx + ws}
+
+
+
 class DiTEngine:
     def __init__(self, model, device=None, precision="bf16", attention=None):
         """model: omnivideo.modules.model.WanModel (parameters are read, never modified).
