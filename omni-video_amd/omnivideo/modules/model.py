@@ -295,6 +295,80 @@ class WanModel(nn.Module):
         # self-attention operands: "auto" = int8 Q K^T in the fp8 mode, bf16 otherwise; "bf16" / "int8" force one
         self.attention_precision = "auto"
 
+    # ---- diffusers-layout directories -----------------------------------------------
+    # The reference's WanModel is a diffusers ModelMixin / ConfigMixin (model.py:293-303): `from_pretrained(dir,
+    # subfolder=...)` reads <dir>/<subfolder>/config.json (the constructor arguments except `ignore_for_config`)
+    # and the weights beside it, `save_pretrained(dir)` writes both.  The same files are read and written here
+    # without the diffusers package, with loaders that execute nothing from the files.
+    CONFIG_NAME = "config.json"
+    WEIGHTS_NAME = "diffusion_pytorch_model"
+    ignore_for_config = ["patch_size", "cross_attn_norm", "qk_norm", "text_dim", "window_size"]
+    _config_keys = ("model_type", "text_len", "in_dim", "dim", "ffn_dim", "freq_dim", "out_dim", "num_heads",
+                    "num_layers", "eps", "use_gradient_checkpointing")
+
+    @property
+    def config(self):
+        return {k: getattr(self, k) for k in self._config_keys}
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, torch_dtype=None, **overrides):
+        """reference: ModelMixin.from_pretrained as called at modules/unified_model.py:42-43.  Reads config.json
+        and `diffusion_pytorch_model.safetensors` (one file, or shards listed by
+        `diffusion_pytorch_model.safetensors.index.json`) or `diffusion_pytorch_model.bin` (a torch.save archive,
+        loaded with weights_only=True).  A local directory only: nothing is downloaded."""
+        import json
+        import os
+        d = os.path.join(pretrained_model_name_or_path, subfolder) if subfolder else pretrained_model_name_or_path
+        cfg_path = os.path.join(d, cls.CONFIG_NAME)
+        if not os.path.isfile(cfg_path):
+            raise OSError(f"{d} does not hold a {cls.CONFIG_NAME}: not a diffusers-layout WanModel directory "
+                          "(hub names are not resolved here, pass a local path)")
+        with open(cfg_path) as fh:
+            raw = json.load(fh)
+        accepted = set(cls._config_keys) | set(cls.ignore_for_config)
+        kw = {k: v for k, v in raw.items() if k in accepted}
+        kw.update(overrides)
+        for k in ("patch_size", "window_size"):
+            if k in kw:
+                kw[k] = tuple(kw[k])
+        model = cls(**kw, skip_init=True)
+        state = {}
+        st, idx, bn = (os.path.join(d, cls.WEIGHTS_NAME + e) for e in (".safetensors", ".safetensors.index.json", ".bin"))
+        if os.path.isfile(st) or os.path.isfile(idx):
+            from safetensors.torch import load_file
+            files = [st]
+            if not os.path.isfile(st):
+                with open(idx) as fh:
+                    files = sorted({os.path.join(d, f) for f in json.load(fh)["weight_map"].values()})
+            for f in files:
+                state.update(load_file(f, device="cpu"))
+        elif os.path.isfile(bn):
+            state = torch.load(bn, map_location="cpu", weights_only=True)
+        else:
+            raise OSError(f"no {cls.WEIGHTS_NAME}.safetensors (or .safetensors.index.json / .bin) in {d}")
+        missing, unexpected = model.load_state_dict(state, strict=False)
+        if missing or unexpected:
+            raise RuntimeError(f"{d}: checkpoint does not match the configuration: {len(missing)} missing keys "
+                               f"(first: {missing[:3]}), {len(unexpected)} unexpected (first: {unexpected[:3]})")
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        return model.eval()
+
+    def save_pretrained(self, save_directory, safe_serialization=True, **unused):
+        """reference: ModelMixin.save_pretrained as called at modules/unified_model.py:280-282."""
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = dict(self.config, _class_name=type(self).__name__)
+        with open(os.path.join(save_directory, self.CONFIG_NAME), "w") as fh:
+            json.dump(cfg, fh, indent=2, sort_keys=True)
+        state = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(state, os.path.join(save_directory, self.WEIGHTS_NAME + ".safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(state, os.path.join(save_directory, self.WEIGHTS_NAME + ".bin"))
+
     # ---- engine management --------------------------------------------------------
     def _weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())

@@ -41,10 +41,8 @@ class UnifiedWanWithMixedConditionModel(nn.Module):
                  skip_init: bool = False):
         super().__init__()
         if isinstance(wan_model_or_ckpt_dir, str):
-            raise NotImplementedError(
-                "loading a diffusers-format WanModel directory is outside this package: construct from "
-                "wan_config and load_state_dict() the checkpoint (the route of the reference CLI, "
-                "tools/inference/generate_omni_v2v.py:495-557)")
+            # reference unified_model.py:42-43: a diffusers-layout directory (config.json + weights)
+            self.wan_model = WanModel.from_pretrained(wan_model_or_ckpt_dir, subfolder=wan_subfolder)
         elif isinstance(wan_model_or_ckpt_dir, WanModel):
             self.wan_model = wan_model_or_ckpt_dir
         elif wan_config is not None:
@@ -183,8 +181,10 @@ class UnifiedWanWithMixedConditionModel(nn.Module):
         return self.wan_model(x, t=t, context=self._mixed, seq_len=seq_len)
 
     def save_pretrained(self, save_dir: str):
+        """reference unified_model.py:280-285: the DiT as a diffusers-layout directory `wan_model/`, the
+        condition builder's own modules as state-dict archives beside it."""
         os.makedirs(save_dir, exist_ok=True)
-        torch.save(self.wan_model.state_dict(), os.path.join(save_dir, "wan_model_pytorch_model.bin"))
+        self.wan_model.save_pretrained(os.path.join(save_dir, "wan_model"))
         if self.visual_context_adapter:
             torch.save(self.visual_context_adapter.state_dict(),
                        os.path.join(save_dir, "visual_context_adapter_pytorch_model.bin"))

@@ -256,22 +256,32 @@ class OmniVideoX2XUnified:
                 block.cross_attn.forward = types.MethodType(sp_cross_attn_forward, block.cross_attn)
             m.wan_model.forward = types.MethodType(sp_dit_forward, m.wan_model)
 
-    def _new_model(self, wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len):
+    def _new_model(self, wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len, checkpoint_dir=None,
+                   subfolder=None):
+        """wan_config given: random-init model of that configuration, to be filled by load_state_dict (the
+        route of the reference CLI, tools/inference/generate_omni_v2v.py:495-557; reference :112-139).
+        wan_config None: the DiT is read from the diffusers-layout directory `checkpoint_dir/subfolder`
+        (reference :140-169 -> modules/unified_model.py:42-43); the condition builder's own modules keep their
+        initial values until a checkpoint is loaded into them, as in the reference."""
+        kw = dict(vlm_in_dim=vlm_in_dim, precision_dtype=self.param_dtype, use_usp=self.use_usp,
+                  use_visual_context_adapter=use_vca, visual_context_adapter_patch_size=vca_patch,
+                  max_context_len=max_context_len)
         if wan_config is None:
-            raise NotImplementedError(
-                "construct with wan_config=... and load_state_dict() the released checkpoint, as the reference "
-                "CLI does (tools/inference/generate_omni_v2v.py:495-557); diffusers-format directories are not read")
-        m = UnifiedWanWithMixedConditionModel(
-            wan_config=wan_config, vlm_in_dim=vlm_in_dim, precision_dtype=self.param_dtype,
-            use_usp=self.use_usp, use_visual_context_adapter=use_vca,
-            visual_context_adapter_patch_size=vca_patch, max_context_len=max_context_len, skip_init=True)
+            if not checkpoint_dir:
+                raise ValueError("without wan_config the models are read from checkpoint_dir: pass one of the two")
+            m = UnifiedWanWithMixedConditionModel.from_pretrained(wan_ckpt_dir=checkpoint_dir, wan_subfolder=subfolder, **kw)
+        else:
+            m = UnifiedWanWithMixedConditionModel(wan_config=wan_config, skip_init=True, **kw)
         m = m.to(self.param_dtype).to(self.device).eval()
         m.wan_model.linear_precision = self.linear_precision
         return m
 
     def _build_models(self, wan_config, checkpoint_dir, vlm_in_dim, use_vca, vca_patch, max_context_len):
-        self.high_noise_model = self._new_model(wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len)
-        self.low_noise_model = self._new_model(wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len)
+        cfg = self.config
+        self.high_noise_model = self._new_model(wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len, checkpoint_dir,
+                                                cfg.get("high_noise_checkpoint", "high_noise_model"))
+        self.low_noise_model = self._new_model(wan_config, vlm_in_dim, use_vca, vca_patch, max_context_len, checkpoint_dir,
+                                               cfg.get("low_noise_checkpoint", "low_noise_model"))
 
     def _load_special_tokens(self, checkpoint_dir):
         """The delimiter-token embeddings (reference :215-226).  The reference unpickles

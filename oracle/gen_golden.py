@@ -4,7 +4,7 @@ modules (loaded by oracle/ref_loader.py from /root/reference) on CPU in float32.
 Only outputs are stored: weights and inputs are regenerated from their names by
 omnivideo.utils.synthetic, so the fixtures stay small.  Run from the repo root:
 
-    python oracle/gen_golden.py [dit] [unipc] [dpm] [t5] [vae] [frames]
+    python oracle/gen_golden.py [dit] [loop] [unipc] [dpm] [t5] [vae] [resample] [frames]
 
 The reference tree exists only in the build container; the committed .npz files are
 what travels.
@@ -156,6 +156,46 @@ def gen_dpm():
     print("dpm.npz:", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def gen_loop():
+    """The reference's denoising loop (x2x_gen_unified.py:474-492) restated line by line around the reference's
+    OWN modules - UnifiedWanWithMixedConditionModel for both guidance branches, FlowUniPCMultistepScheduler
+    constructed and stepped as at :409-416 and :486-491 - on CPU in fp32 (`generate` itself hard-codes a CUDA
+    device and generator, :48,339).  Also WanLayerNorm with and without its affine parameters (model.py:87-97)."""
+    ns = ref_loader.load()
+    cfg = syn.dit_config("tiny")
+    sd = syn.make_unified_state_dict(cfg, seed=0)
+    special = syn.make_special_tokens(cfg, seed=0)
+    inp = tiny_inputs()
+    out = {}
+    with torch.no_grad():
+        m = build_ref_unified(ns, cfg, sd, cfg["text_len"])
+        sched = ns.unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        sched.set_timesteps(4, device="cpu", shift=5.0)
+        ar_null = torch.zeros(2, cfg["vlm_in_dim"]) + 1e-6
+        arg_c = dict(context=[inp["text"]], ar_vision_input=[inp["ar"][0]], visual_emb=inp["visual"],
+                     special_token_dict=special, seq_len=72)
+        arg_null = dict(context=[inp["text_null"]], ar_vision_input=[ar_null], visual_emb=inp["visual"],
+                        special_token_dict=special, seq_len=72)
+        latents = [syn.randn("gen.noise", (16, 3, 8, 12), 11)]
+        traj = []
+        for t in sched.timesteps:
+            timestep = torch.stack([t])
+            noise_pred_cond = m(latents, t=timestep, **arg_c)[0]
+            noise_pred_uncond = m(latents, t=timestep, **arg_null)[0]
+            noise_pred = noise_pred_uncond + 3.0 * (noise_pred_cond - noise_pred_uncond)
+            temp_x0 = sched.step(noise_pred.unsqueeze(0), t, latents[0].unsqueeze(0), return_dict=False)[0]
+            latents = [temp_x0.squeeze(0)]
+            traj.append(latents[0].clone())
+        out["cfg_unipc_traj_4"] = torch.stack(traj)
+        out["timesteps_4"] = sched.timesteps.clone()
+        x = syn.randn("probe.x", (1, 80, cfg["dim"]), 3)
+        ln = ns.model.WanLayerNorm(cfg["dim"], eps=cfg["eps"], elementwise_affine=False)
+        out["layernorm_plain"] = ln(x)[0]
+        out["layernorm_affine"] = m.wan_model.blocks[1].norm3(x)[0]
+    np.savez_compressed(os.path.join(GOLD, "loop_tiny.npz"), **{k: v.detach().numpy() for k, v in out.items()})
+    print("loop_tiny.npz:", {k: tuple(v.shape) for k, v in out.items()})
+
+
 def gen_t5():
     """Outputs of the reference T5Encoder (tiny configuration, shared_pos=False, eval mode) in
     float32 and with the module cast to bf16, for two batches of token ids."""
@@ -194,11 +234,13 @@ def gen_frames():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dit", "unipc", "dpm", "t5", "vae", "frames"]
+    which = sys.argv[1:] or ["dit", "loop", "unipc", "dpm", "t5", "vae", "resample", "frames"]
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     if "dit" in which:
         gen_dit()
+    if "loop" in which:
+        gen_loop()
     if "unipc" in which:
         gen_unipc()
     if "dpm" in which:
@@ -210,3 +252,6 @@ if __name__ == "__main__":
     if "vae" in which:
         from oracle import gen_golden_vae
         gen_golden_vae.main()
+    if "resample" in which:
+        from oracle import gen_golden_vae
+        gen_golden_vae.resample_probes()

@@ -17,6 +17,49 @@ from oracle import ref_loader                     # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+def build(ns):
+    V = ns.vae2_1
+    cfg = syn.vae_config("tiny")
+    sd = syn.make_vae_state_dict(cfg, 0)
+    m = V.WanVAE_(dim=cfg["dim"], z_dim=cfg["z_dim"], dim_mult=list(cfg["dim_mult"]),
+                  num_res_blocks=cfg["num_res_blocks"], attn_scales=[],
+                  temperal_downsample=list(cfg["temperal_downsample"]), dropout=0.0).eval()
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def resample_probes():
+    """The four Resample modes (vae2_1.py:65-159) of the tiny VAE as separate probes, streamed over three
+    consecutive chunks each with the module's own feature cache: downsample2d / downsample3d are the encoder's
+    (chunks of 1, 4, 2 frames: the first passes the temporal convolution untouched, :142-158), upsample3d /
+    upsample2d the decoder's (three chunks of one latent frame: the first stores the 'Rep' sentinel and skips the
+    temporal convolution, the second convolves against zero left context, the third against the cached frames,
+    :102-136).  -> tests/golden/vae_resample.npz"""
+    ns = ref_loader.load()
+    V = ns.vae2_1
+    m = build(ns)
+    mods = {}
+    for name, seq in (("encoder.downsamples", m.encoder.downsamples), ("decoder.upsamples", m.decoder.upsamples)):
+        for i, layer in enumerate(seq):
+            if isinstance(layer, V.Resample):
+                mods.setdefault(layer.mode, (f"{name}.{i}", layer))
+    assert sorted(mods) == ["downsample2d", "downsample3d", "upsample2d", "upsample3d"], sorted(mods)
+    out = {}
+    with torch.no_grad():
+        for mode, (name, layer) in sorted(mods.items()):
+            cin = layer.dim
+            chunks = ((0, 1), (1, 5), (5, 7)) if mode.startswith("down") else ((0, 1), (1, 2), (2, 3))
+            x = syn.randn(f"vae.resample.{mode}", (1, cin, chunks[-1][1], 6, 8), 5)
+            cache, ys = [None], []
+            for a, b in chunks:
+                ys.append(layer(x[:, :, a:b], cache, [0]))
+            out[mode] = torch.cat(ys, 2)[0]
+            out[mode + "_module"] = np.array(name)
+    np.savez_compressed(os.path.join(GOLD, "vae_resample.npz"), **{k: (v.numpy() if hasattr(v, "numpy") else v)
+                                                                   for k, v in out.items()})
+    print("vae_resample.npz:", {k: tuple(getattr(v, "shape", ())) for k, v in out.items()})
+
+
 def main():
     ns = ref_loader.load()
     V = ns.vae2_1

@@ -188,6 +188,27 @@ def test_vae_decode_full_size_causality():
     assert torch.equal(head, full[:, :17])
 
 
+def test_vae_encode_full_size_causality():
+    """Encode of a 49-frame 480p clip with the full-width VAE (random weights), the V2V input path
+    (reference tools/inference/generate_omni_v2v.py:609-614 -> vae2_1.py:515-541): 13 chunks of 1,4,4,...
+    frames, the first of which passes the temporal down-sampling convolutions untouched while every later one
+    convolves with the cached last frame of its predecessor.  Finite, of the latent shape the sampler expects,
+    and causal: encoding the first 17 frames alone gives exactly the first 5 latent frames of the full encode."""
+    from omnivideo.modules.vae2_1 import Wan2_1_VAE
+    with torch.device("cuda"):
+        vae = Wan2_1_VAE(z_dim=16, vae_pth=None, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(43)
+    clip = torch.rand(3, 49, 480, 832, device="cuda", generator=g) * 2 - 1
+    full = vae.encode([clip])[0]
+    assert tuple(full.shape) == (16, 13, 60, 104) and full.dtype == torch.float32 and torch.isfinite(full).all()
+    assert float(full.std()) > 1e-3                              # not a constant
+    head = vae.encode([clip[:, :17].contiguous()])[0]
+    assert tuple(head.shape) == (16, 5, 60, 104)
+    assert torch.equal(head, full[:, :5])
+    again = vae.encode([clip])[0]                                # the chunk cache is reset between calls
+    assert torch.equal(again, full)
+
+
 def test_full_depth_1p3b_forward_at_cpu_reference_case_shape():
     """The whole 30-layer 1.3B DiT at the shape of the reference's CPU-runnable case (17 frames 256x256:
     latent [16,5,32,32], 1 280 tokens, text_len 512) against the oracle forward in its bf16 flow - depth

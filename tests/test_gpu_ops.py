@@ -67,6 +67,26 @@ def test_layernorm_modulate(H, C, M):
                       flip_atol=0.04)
 
 
+def test_layernorm_against_reference_module_golden(H, golden_dir):
+    """The LayerNorm kernel, fp32 output, against the reference's WanLayerNorm itself (tests/golden/loop_tiny.npz;
+    reference model.py:87-97): plain, and with the affine parameters of a block's norm3 (bf16-rounded weights on
+    both sides of the comparison are not available there, so the affine case carries the bf16 rounding of the
+    parameters: 2^-8 relative)."""
+    import os
+    import numpy as np
+    G = np.load(os.path.join(golden_dir, "loop_tiny.npz"))
+    cfg = syn.dit_config("tiny")
+    sd = syn.make_unified_state_dict(cfg, 0)
+    x = syn.randn("probe.x", (1, 80, cfg["dim"]), 3)[0]
+    out = torch.empty(80, cfg["dim"], device="cuda")
+    H.layernorm_modulate(dev(x), out, cfg["eps"])
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(G["layernorm_plain"]), rtol=1e-5, atol=1e-5)
+    w, b = sd["wan_model.blocks.1.norm3.weight"], sd["wan_model.blocks.1.norm3.bias"]
+    H.layernorm_modulate(dev(x), out, cfg["eps"], weight=dev(w, BF16), bias=dev(b, BF16))
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(G["layernorm_affine"]), rtol=2.0 ** -7, atol=2.0 ** -7)
+    torch.testing.assert_close(out.cpu(), O.layer_norm(x, cfg["eps"], rb(w), rb(b)), rtol=1e-5, atol=1e-5)
+
+
 def test_layernorm_rejects_bad_width(H):
     with pytest.raises(RuntimeError, match="multiple of 256"):
         H.layernorm_modulate(torch.zeros(4, 100, device="cuda"), torch.zeros(4, 100, device="cuda"), 1e-6)

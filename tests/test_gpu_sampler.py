@@ -1,5 +1,7 @@
 """The fused guidance + UniPC kernel and the whole denoising loop (eager and graph-replayed)
 against the oracle sampler driving the oracle DiT."""
+import os
+
 import pytest
 import torch
 
@@ -133,6 +135,26 @@ def test_generate_loop_matches_oracle(use_graph):
     ref = U.sample_loop(fc, fu, noise.clone(), steps, shift, guide)
     rel = float((lat.float().cpu() - ref.float()).norm() / ref.float().norm())
     check_rel("test_generate_loop_matches_oracle", rel, 6e-3)      # observed 1.9e-3
+
+
+def test_generate_loop_vs_reference_loop_golden(golden_dir):
+    """The same 4-step guided sampling against the trajectory of the REFERENCE's own modules driven as its loop
+    drives them (tests/golden/loop_tiny.npz, fp32 on CPU): the distance is that of the bf16 flow from the fp32
+    flow accumulated over four steps - the pinned leg of the loop-level parity."""
+    import numpy as np
+    cfg = syn.dit_config("tiny")
+    sd, sp = syn.make_unified_state_dict(cfg, 0), syn.make_special_tokens(cfg, 0)
+    text, text_null = syn.randn("in.text", (10, cfg["text_dim"]), 1), syn.randn("in.text_null", (6, cfg["text_dim"]), 1)
+    ar, visual = syn.randn("in.ar", (1, 7, cfg["vlm_in_dim"]), 1), syn.randn("in.visual", (1, 16, 3, 8, 12), 1)
+    noise = syn.randn("gen.noise", (16, 3, 8, 12), 11)
+    pipe = _pipeline(cfg, sd, sp)
+    lat = pipe.generate("", precomputed_context=text.to(BF16), precomputed_context_null=text_null.to(BF16),
+                        ar_vision_input=[ar[0].cuda().to(BF16)], visual_emb=visual.cuda(), size=(96, 64),
+                        frame_num=9, shift=5.0, sampling_steps=4, guide_scale=3.0, seed=1, noise=noise.to(BF16),
+                        return_latents=True)
+    want = torch.from_numpy(np.load(os.path.join(golden_dir, "loop_tiny.npz"))["cfg_unipc_traj_4"])[-1]
+    rel = float((lat.float().cpu() - want).norm() / want.norm())
+    check_rel("generate 4 steps vs the reference loop's fp32 golden", rel, 2.5e-2)
 
 
 def test_generate_loop_dpmpp_matches_oracle():

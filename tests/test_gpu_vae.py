@@ -187,6 +187,30 @@ def test_decode(vae, G, tl, hw):
     torch.testing.assert_close(x.cpu(), G[f"decode_{tl}"], rtol=RTOL_NET, atol=ATOL_NET)
 
 
+@pytest.mark.parametrize("mode", ["downsample2d", "downsample3d", "upsample2d", "upsample3d"])
+def test_resample_modes_streamed_over_three_chunks(vae, golden_dir, mode):
+    """The runner's Resample paths (first-chunk pass-through of the temporal down-sampling; 'Rep' / zero-context
+    / cached-context sequence of the temporal up-sampling), three consecutive chunks each, against the
+    reference module's own output (tests/golden/vae_resample.npz; reference vae2_1.py:102-158)."""
+    v, sd, lay = vae
+    GR = dict(np.load(os.path.join(golden_dir, "vae_resample.npz")).items())
+    name, want = str(GR[mode + "_module"]), torch.from_numpy(GR[mode])
+    chunks = ((0, 1), (1, 5), (5, 7)) if mode.startswith("down") else ((0, 1), (1, 2), (2, 3))
+    layer = v.model.get_submodule(name)
+    assert layer.mode == mode
+    cin = sd[name + ".resample.1.weight"].shape[1]
+    x = syn.randn(f"vae.resample.{mode}", (1, cin, chunks[-1][1], 6, 8), 5)[0]
+    run = v.model.runner()
+    run.reset()
+    fn = run.downsample if mode.startswith("down") else run.upsample
+    with torch.no_grad():
+        ys = [fn(cl(x[:, a:b]), layer, name) for a, b in chunks]
+    run.reset()
+    got = cf(torch.cat(ys, dim=0))
+    assert tuple(got.shape) == tuple(want.shape)
+    torch.testing.assert_close(got, want, rtol=RTOL, atol=ATOL)
+
+
 def test_decode_encode_round_trip_shapes(vae):
     """decode -> encode keeps the latent geometry (size-independent property)."""
     v, _, _ = vae

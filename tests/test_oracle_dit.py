@@ -159,3 +159,38 @@ def test_sampled_row_forward_equals_whole_forward(flow):
     # fp32: summation order of the row-subset matmuls only; bf16 flow: that order can flip a rounding
     tol = dict(rtol=1e-5, atol=1e-6) if flow == "fp32" else dict(rtol=2e-3, atol=5e-5)
     torch.testing.assert_close(got, want, **tol)
+
+
+@pytest.fixture(scope="module")
+def GL(golden_dir):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "loop_tiny.npz")).items()}
+
+
+def test_layernorm(GL, W):
+    """WanLayerNorm without and with affine parameters (reference model.py:87-97; norm3 of a block)."""
+    cfg, sd, _ = W
+    x = syn.randn("probe.x", (1, 80, cfg["dim"]), 3)[0]
+    close(O.layer_norm(x, cfg["eps"]), GL["layernorm_plain"])
+    close(O.layer_norm(x, cfg["eps"], sd["wan_model.blocks.1.norm3.weight"], sd["wan_model.blocks.1.norm3.bias"]),
+          GL["layernorm_affine"])
+
+
+def test_guided_unipc_trajectory_through_the_reference_loop(GL, W):
+    """Four guided UniPC steps of the tiny mixed-condition model: the oracle's loop (forward of both guidance
+    branches, combine, scheduler step) against the trajectory the reference's own modules produce when driven
+    as x2x_gen_unified.py:474-492 drives them (oracle/gen_golden.py: gen_loop), after every step."""
+    from oracle import unipc as U
+    cfg, sd, special = W
+    inp = inputs()
+    ar_null = torch.zeros(2, cfg["vlm_in_dim"]) + 1e-6
+    sched = U.UniPC(4, 5.0)
+    assert [int(t) for t in sched.timesteps] == GL["timesteps_4"].tolist()
+    lat = syn.randn("gen.noise", (16, 3, 8, 12), 11)
+    with torch.no_grad():
+        for i, t in enumerate(sched.timesteps):
+            c = O.unified_forward(lat, int(t), sd, cfg, 72, "fp32", text=inp["text"], ar_vision=inp["ar"][0],
+                                  visual=inp["visual"], special=special)
+            u = O.unified_forward(lat, int(t), sd, cfg, 72, "fp32", text=inp["text_null"], ar_vision=ar_null,
+                                  visual=inp["visual"], special=special)
+            lat = sched.step(u + 3.0 * (c - u), lat)
+            close(lat, GL["cfg_unipc_traj_4"][i], 5e-4, 5e-5)

@@ -51,3 +51,30 @@ def test_resblock_streaming(G, W):
         for a, b in ((0, 1), (1, 5), (5, 7)):
             ys.append(V.res_block(x[:, a:b], sd, "encoder.downsamples.0", cache))
     torch.testing.assert_close(torch.cat(ys, 1), G["resblock_stream"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def GR(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "vae_resample.npz")).items())
+
+
+@pytest.mark.parametrize("mode", ["downsample2d", "downsample3d", "upsample2d", "upsample3d"])
+def test_resample_modes_streamed_over_three_chunks(GR, W, mode):
+    """Each Resample mode on its own, three consecutive chunks through the oracle's feature cache, against the
+    reference module's output (oracle/gen_golden_vae.py: resample_probes): the first-chunk pass-through of the
+    temporal down-sampling, the 'Rep' sentinel / zero-context / cached-context sequence of the temporal
+    up-sampling (reference vae2_1.py:102-158)."""
+    cfg, sd, lay = W
+    name = str(GR[mode + "_module"])
+    want = torch.from_numpy(GR[mode])
+    chunks = ((0, 1), (1, 5), (5, 7)) if mode.startswith("down") else ((0, 1), (1, 2), (2, 3))
+    cin = sd[name + ".resample.1.weight"].shape[1]
+    x = syn.randn(f"vae.resample.{mode}", (1, cin, chunks[-1][1], 6, 8), 5)[0]
+    fn = V.downsample if mode.startswith("down") else V.upsample
+    cache, ys = {}, []
+    with torch.no_grad():
+        for a, b in chunks:
+            ys.append(fn(x[:, a:b], sd, name, mode, cache))
+    got = torch.cat(ys, 1)
+    assert tuple(got.shape) == tuple(want.shape)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
