@@ -154,7 +154,7 @@ def test_generate_loop_vs_reference_loop_golden(golden_dir):
                         return_latents=True)
     want = torch.from_numpy(np.load(os.path.join(golden_dir, "loop_tiny.npz"))["cfg_unipc_traj_4"])[-1]
     rel = float((lat.float().cpu() - want).norm() / want.norm())
-    check_rel("generate 4 steps vs the reference loop's fp32 golden", rel, 2.5e-2)
+    check_rel("generate 4 steps vs the reference loop's fp32 golden", rel, 1.4e-2)      # observed 4.5e-3
 
 
 def test_generate_loop_dpmpp_matches_oracle():
