@@ -225,16 +225,22 @@ def qkv_norm_rope(qkv, wq, wk, head_dim, eps, rope, rows_per_sample, tok_offset,
 
 
 def qkv_norm_rope_scatter(qkv, wq, wk, head_dim, eps, rope, rows_per_sample, tok_offset, n_rope, grid, block_ptrs,
-                          total_rows):
+                          total_rows, samples_total=None):
     """qkv_norm_rope whose column block j (C / p columns: the heads of rank j) goes to the buffer at
     block_ptrs[j] (int64 device tensor of p addresses): each a [3, samples, total_rows, C/p] bf16 receive
-    buffer already advanced to this rank's first row.  The caller owns the validity of the addresses."""
+    buffer already advanced to this rank's first row.  The caller owns the validity of the addresses.
+    samples_total: the receive buffers' sample count when the rows passed are only some of the samples (the
+    addresses are then advanced to the first of them as well)."""
     M, C3, ld = _rows(qkv)
     C = C3 // 3
     p = block_ptrs.numel()
     if wq.numel() != C or wk.numel() != C or C % p or M % rows_per_sample:
         raise ValueError("qkv_norm_rope_scatter: shape mismatch")
     cb, ns = C // p, M // rows_per_sample
+    if samples_total is not None:
+        if samples_total < ns:
+            raise ValueError("qkv_norm_rope_scatter: samples_total smaller than the samples passed")
+        ns = int(samples_total)
     _call("ovd_qkv_norm_rope_scatter_bf16", _ptr(qkv, BF16), ld, _ptr(wq, BF16), _ptr(wk, BF16), _ptr(rope, F32),
           rope.shape[1], _ptr(block_ptrs, torch.int64), cb, ns * total_rows * cb, cb, total_rows * cb, M, C, head_dim,
           float(eps), rows_per_sample, tok_offset, n_rope, grid[0], grid[1], grid[2], _stream())

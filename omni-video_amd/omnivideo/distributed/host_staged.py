@@ -26,6 +26,14 @@ class HostStagedComm:
         dist.all_to_all_single(r, src, group=self.group)
         recv.copy_(r.view(recv.dtype).reshape(recv.shape))
 
+    # split-phase form of engine.TorchGroupComm: nothing runs beside a host-staged exchange, so the
+    # exchange happens at start and wait() has nothing left to do
+    def all_to_all_start(self, recv, send, tag):
+        self.all_to_all(recv, send)
+
+    def wait(self, tag):
+        pass
+
     def all_reduce_sum(self, t):
         c = t.cpu()
         dist.all_reduce(c, group=self.group)

@@ -85,6 +85,17 @@ class TorchGroupComm:
     def all_to_all(self, recv, send):
         dist.all_to_all_single(recv, send, group=self.group)
 
+    # split-phase form: the exchange is queued behind the work already on the current stream and runs on the
+    # collective library's own stream; wait() makes the current stream wait for it.  What is launched between
+    # the two runs beside the exchange.
+    def all_to_all_start(self, recv, send, tag):
+        if not hasattr(self, "_pending"):
+            self._pending = {}
+        self._pending[tag] = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+
+    def wait(self, tag):
+        self._pending.pop(tag).wait()
+
     def all_reduce_sum(self, t):
         dist.all_reduce(t, group=self.group)
 
@@ -243,6 +254,8 @@ class DiTEngine:
         self.head_mod = w(model.head.modulation).reshape(2, self.dim)
         self._shape = None
         self.timing = None
+        import os
+        self.sp_overlap = os.environ.get("OVD_SP_OVERLAP", "1") != "0"
 
     # ------------------------------------------------------------------ workspaces
     def plan(self, grid, seq_len, nb, comm=None):
@@ -288,6 +301,8 @@ class DiTEngine:
         self.rope = build_rope_table(self.head_dim, max(grid), dev)
         # self-attention runs over the full sequence for N / sp heads: workspace for its tail balancing
         ws = H.flash_attn_workspace_bytes(nb, seq_len, N // sp, n_tok)
+        if sp > 1:      # the sharded forward may launch self-attention one guidance branch at a time
+            ws = max(ws, H.flash_attn_workspace_bytes(1, seq_len, N // sp, n_tok))
         self.attn_ws = torch.empty(ws, dtype=torch.uint8, device=dev) if ws > 0 else None
         if self.attention == "int8":         # self-attention operands: full sequence, this rank's heads
             self.q8, self.k8 = e(nb, seq_len, C // sp, dt=torch.int8), e(nb, seq_len, C // sp, dt=torch.int8)
@@ -311,6 +326,7 @@ class DiTEngine:
                 self._sp_shared = (self.sp_qkv, self.sp_o)
                 row0_el = rank * S * Cs
                 self._sp_qkv_tab = comm.table(self.sp_qkv, row0_el)
+                self._sp_qkv_tabs = [comm.table(self.sp_qkv, b * seq_len * Cs + row0_el) for b in range(nb)]
                 self._sp_o_tabs = [comm.table(self.sp_o, b * seq_len * Cs + row0_el) for b in range(nb)]
             else:
                 self.sp_send = ex(3, nb, sp, S, Cs)   # q|k|v of my rows, split by destination head group
@@ -318,6 +334,8 @@ class DiTEngine:
                 self.sp_o = ex(nb, seq_len, Cs)       # attention output, full sequence, my head group
                 self.sp_orecv = e(nb, sp, S, Cs)      # every head group's output for my rows
                 self._sp_shared = (self.sp_send, self.sp_o) if shared is not None else ()
+        if sp > 1 and getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)       # carries one branch's exchange beside the other's attention
         self.grid, self.seq_len, self.nb, self.n_tok = tuple(grid), seq_len, nb, n_tok
         self.comm, self.sp, self.S, self.row0 = comm, sp, S, rank * S
         self._shape = key
@@ -347,22 +365,26 @@ class DiTEngine:
         return ContextCache(kv, text_len, max(int(c.reshape(-1, self.text_dim).shape[0]) for c in contexts))
 
     # ------------------------------------------------------------------ attention variants
-    def _self_attention(self, q4, k4, v4, att4):
+    def _self_attention(self, q4, k4, v4, att4, branch=None):
+        """branch: None = all guidance branches in one launch; b = branch b alone."""
         int8 = self.attention == "int8"
+        sl = slice(None) if branch is None else slice(branch, branch + 1)
+        q4, k4, v4, att4 = q4[sl], k4[sl], v4[sl], att4[sl]
         if int8:
-            q8, k8 = (t.unflatten(2, (q4.shape[2], q4.shape[3])) for t in (self.q8, self.k8))
-            H.quant_heads_i8(q4, q8, self.q8_scale, 1)
-            H.quant_heads_i8(k4, k8, self.k8_scale, 64)
+            q8, k8 = (t[sl].unflatten(2, (q4.shape[2], q4.shape[3])) for t in (self.q8, self.k8))
+            q8s, k8s = self.q8_scale[sl], self.k8_scale[sl]
+            H.quant_heads_i8(q4, q8, q8s, 1)
+            H.quant_heads_i8(k4, k8, k8s, 64)
         if self.timing is not None:      # profiling hook: events around the dominant kernel
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         if int8:
-            H.flash_attn_qk8(q8, self.q8_scale, k8, self.k8_scale, v4, att4, k_len=self.n_tok, workspace=self.attn_ws)
+            H.flash_attn_qk8(q8, q8s, k8, k8s, v4, att4, k_len=self.n_tok, workspace=self.attn_ws)
         else:
             H.flash_attn(q4, k4, v4, att4, k_len=self.n_tok, workspace=self.attn_ws)
         if self.timing is not None:
             ev[1].record()
-            self.timing.append(ev)
+            self.timing.append(ev + (q4.shape[0],))          # (start, end, guidance branches in the launch)
 
     def _self_attention_sp(self, L):
         """Ulysses exchange around the attention kernel (reference ulysses.py:41-55).  The kernel that
@@ -371,8 +393,48 @@ class DiTEngine:
         what arrives IS the full sequence for this rank's heads, which the attention kernel reads in
         place; its output goes back the same way and one gather kernel restores token rows.  No packing
         or unpacking copies (the reference chunks, copies and concatenates around each of its four
-        all-to-alls, util.py:106-109)."""
+        all-to-alls, util.py:106-109).
+
+        The two guidance branches are independent until the guidance combine, so with `overlap` (default;
+        OVD_SP_OVERLAP=0 restores the serial order) attention runs one branch at a time and the other branch's
+        exchange runs beside it: the second branch's q | k | v travel while the first branch attends, the
+        first branch's output returns while the second attends.  The reference issues everything in sequence
+        on one stream (ulysses.py:41-55)."""
         N, D, nb, S, sp = self.num_heads, self.head_dim, self.nb, self.S, self.sp
+        overlap = nb == 2 and self.sp_overlap
+        q4, k4, v4 = (self.sp_qkv[i].unflatten(2, (N // sp, D)) for i in range(3))
+        o4 = self.sp_o.unflatten(2, (N // sp, D))
+        if self.sp_direct and overlap:
+            # Peer-mapped, overlapped.  Three barriers per layer on the main stream; a barrier vouches for what its
+            # rank issued on the main stream before it, so work on the side stream is joined before the barrier
+            # that has to cover it.
+            #   B1: every rank's q | k | v of branch 0 have landed               -> attention of branch 0
+            #   B2: ... attention of branch 0 is done, q | k | v of branch 1 have landed -> attention of branch 1,
+            #       and (side stream) the gather of branch 0's output from the peers
+            #   B3: ... attention of branch 1 is done                            -> gather of branch 1
+            # Overwrites: a peer's q | k | v of branch b are rewritten (next layer) after B2 / B3 of this layer,
+            # i.e. after that peer's attention of branch b; a peer's output of branch 0 is rewritten by its next
+            # attention of branch 0, which follows its B1 of the next layer, which waits for this rank's B1, which
+            # this rank issues after joining its side stream (gather of branch 0 done).
+            main, side = torch.cuda.current_stream(), self._side
+            qkv_b = [self.qkv[b] for b in range(nb)]
+            args = (L["nq"], L["nk"], D, self.eps, self.rope, S, self.row0, self.n_tok, self.grid)
+            H.qkv_norm_rope_scatter(qkv_b[0], *args, self._sp_qkv_tabs[0], self.seq_len, samples_total=nb)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                H.qkv_norm_rope_scatter(qkv_b[1], *args, self._sp_qkv_tabs[1], self.seq_len, samples_total=nb)
+            self.comm.barrier()                                   # B1
+            self._self_attention(q4, k4, v4, o4, branch=0)
+            main.wait_stream(side)
+            self.comm.barrier()                                   # B2
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                H.gather_col_blocks_from(self._sp_o_tabs[0], self.att[0], first=self.comm.rank + 1)
+            self._self_attention(q4, k4, v4, o4, branch=1)
+            self.comm.barrier()                                   # B3
+            H.gather_col_blocks_from(self._sp_o_tabs[1], self.att[1], first=self.comm.rank + 1)
+            main.wait_stream(side)
+            return
         if self.sp_direct:
             # Peer-mapped exchange: q, k, v go from the kernel that produces them into every peer's attention
             # operands; after the barrier all of mine have arrived.  The second barrier says every rank's
@@ -380,19 +442,32 @@ class DiTEngine:
             H.qkv_norm_rope_scatter(self.qkv.view(nb * S, -1), L["nq"], L["nk"], D, self.eps, self.rope, S, self.row0,
                                     self.n_tok, self.grid, self._sp_qkv_tab, self.seq_len)
             self.comm.barrier()
-            q4, k4, v4 = (self.sp_qkv[i].unflatten(2, (N // sp, D)) for i in range(3))
-            self._self_attention(q4, k4, v4, self.sp_o.unflatten(2, (N // sp, D)))
+            self._self_attention(q4, k4, v4, o4)
             self.comm.barrier()
             for b in range(nb):
                 H.gather_col_blocks_from(self._sp_o_tabs[b], self.att[b], first=self.comm.rank + 1)
             return
         H.qkv_norm_rope(self.qkv.view(nb * S, -1), L["nq"], L["nk"], D, self.eps, self.rope, S, self.row0,
                         self.n_tok, self.grid, send=self.sp_send)
+        if overlap and hasattr(self.comm, "all_to_all_start"):
+            # Collective library, split-phase: all six q | k | v exchanges are queued at once (they run in this
+            # order on the library's stream); attention of branch 0 needs the first three only.
+            for b in range(nb):
+                for part in range(3):
+                    self.comm.all_to_all_start(self.sp_qkv[part, b].view(sp, S, -1), self.sp_send[part, b], ("qkv", b, part))
+            for b in range(nb):
+                for part in range(3):
+                    self.comm.wait(("qkv", b, part))
+                self._self_attention(q4, k4, v4, o4, branch=b)
+                self.comm.all_to_all_start(self.sp_orecv[b], self.sp_o[b].view(sp, S, -1), ("o", b))
+            for b in range(nb):
+                self.comm.wait(("o", b))
+                H.gather_col_blocks(self.sp_orecv[b], self.att[b])
+            return
         for part in range(3):
             for b in range(nb):
                 self.comm.all_to_all(self.sp_qkv[part, b].view(sp, S, -1), self.sp_send[part, b])
-        q4, k4, v4 = (self.sp_qkv[i].unflatten(2, (N // sp, D)) for i in range(3))
-        self._self_attention(q4, k4, v4, self.sp_o.unflatten(2, (N // sp, D)))
+        self._self_attention(q4, k4, v4, o4)
         for b in range(nb):
             self.comm.all_to_all(self.sp_orecv[b], self.sp_o[b].view(sp, S, -1))
             H.gather_col_blocks(self.sp_orecv[b], self.att[b])

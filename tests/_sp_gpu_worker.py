@@ -137,7 +137,7 @@ def case_peer(outdir, rank, world):
     torch.save(dict(ok=True), os.path.join(outdir, f"rank{rank}.pt"))
 
 
-def engine_case(precision, comm=None, replays=0, shape="tiny4"):
+def engine_case(precision, comm=None, replays=0, shape="tiny4", overlap=None):
     """One DiT forward, optionally sharded over `comm` and replayed from a graph.  shape "tiny4": a 4-head
     tiny model over seq_len 80 (8 padding rows; the inputs of tests/test_gpu_sequence_parallel.py); "a14b":
     one layer of the A14B width (C = 5120, 40 heads, FFN 13 824) on the full 81-frame 720p grid, 75 600
@@ -163,6 +163,8 @@ def engine_case(precision, comm=None, replays=0, shape="tiny4"):
             syn.randn("in.text_null", (6, cfg["text_dim"]), 1).cuda().to(BF16)]
     ts = torch.tensor([640.0], dtype=torch.float64, device="cuda")
     eng = DiTEngine(wm, precision=precision)
+    if overlap is not None:                # False: the serial order of exchanges and attention
+        eng.sp_overlap = overlap
     eng.plan(grid, seq_len, 2, comm=comm)
     cache = eng.encode_context(ctxs, wm.text_len)
     out = torch.empty(2, *lat_shape, device="cuda")
@@ -190,6 +192,8 @@ def case_peer_engine(outdir, rank, world):
         for direct in (True, False):
             comm = PeerMappedComm(None, timeout_s=20, direct=direct)
             res[f"{precision}_{'direct' if direct else 'pull'}"] = engine_case(precision, comm, replays=3).cpu()
+            if direct:     # the same exchange with both guidance branches in one attention launch, nothing beside it
+                res[f"{precision}_direct_serial"] = engine_case(precision, comm, replays=2, overlap=False).cpu()
             comm.check()
             comm.close()
     torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))

@@ -83,7 +83,8 @@ def test_peer_mapped_collectives_two_processes(tmp_path):
 
 def test_peer_mapped_engine_forward_four_processes_equals_unsharded(tmp_path):
     """4 ranks x 1 head each, 80 rows with 8 padding rows: every rank's full output equals the unsharded
-    forward bit for bit, with the kernels addressing the peers directly and with the copy-kernel exchange,
+    forward bit for bit, with the kernels addressing the peers directly (one guidance branch's exchange on a
+    second stream beside the other's attention, and the serial order) and with the copy-kernel exchange,
     bf16 and reduced precision, eager and replayed as one graph."""
     import _sp_gpu_worker as W
     launch("_sp_gpu_worker.py", ["peer_engine", str(tmp_path)], 4, timeout=240)
@@ -91,7 +92,7 @@ def test_peer_mapped_engine_forward_four_processes_equals_unsharded(tmp_path):
         want = {p: W.engine_case(p).cpu() for p in ("bf16", "fp8")}
     for r in range(4):
         got = torch.load(tmp_path / f"rank{r}.pt", weights_only=True)
-        assert sorted(got) == ["bf16_direct", "bf16_pull", "fp8_direct", "fp8_pull"]
+        assert sorted(got) == ["bf16_direct", "bf16_direct_serial", "bf16_pull", "fp8_direct", "fp8_direct_serial", "fp8_pull"]
         for name, t in got.items():
             assert torch.equal(t, want[name.split("_")[0]]), f"rank {r} {name}"
 
