@@ -59,7 +59,9 @@ int ovd_impl_cfg_dpm_step(const float*, const float*, const void*, float*, float
                           int, long, int, hipStream_t);
 int ovd_impl_step_advance(int*, hipStream_t);
 int ovd_impl_split_weights(const float*, uint16_t*, long, int, hipStream_t);
-int ovd_impl_conv3d_cl(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+int ovd_impl_act_split(const float*, const float*, int, uint16_t*, long, int, hipStream_t);
+int ovd_impl_conv3d_cl(const float*, const float*, const float*, const uint16_t*, const uint16_t*, const uint16_t*,
+                       const float*, const float*, const float*, const float*,
                        int, const float*, const uint16_t*, const float*, const float*, float*, int, int, int, int, int, int, int, int,
                        int, int, int, int, int, int, hipStream_t);
 int ovd_impl_voxel_rnorm(const float*, float*, long, int, hipStream_t);
@@ -368,7 +370,8 @@ int ovd_vae_conv3d_f32(const float* x, const float* prev2, const float* prev1, c
     NONNULL(x); NONNULL(w); NONNULL(out);
     OVD_REQUIRE((prev2 == nullptr || rnorm == nullptr) || rnorm_prev2 != nullptr, "conv3d: prev2 needs its voxel norms");
     OVD_REQUIRE((prev1 == nullptr || rnorm == nullptr) || rnorm_prev1 != nullptr, "conv3d: prev1 needs its voxel norms");
-    return ovd_impl_conv3d_cl(x, prev2, prev1, rnorm, rnorm_prev2, rnorm_prev1, gamma, silu, w, nullptr, bias, resid, out,
+    return ovd_impl_conv3d_cl(x, prev2, prev1, nullptr, nullptr, nullptr, rnorm, rnorm_prev2, rnorm_prev1, gamma, silu, w,
+                              nullptr, bias, resid, out,
                               T, H, W, Cin, Cout, KT, KH, KW, stride_t, stride_hw, pad_t, pad_hw, upsample2,
                               time_interleave, ST(stream));
 }
@@ -386,9 +389,25 @@ int ovd_vae_conv3d_sw_f32(const float* x, const float* prev2, const float* prev1
     NONNULL(x); NONNULL(w_split); NONNULL(out);
     OVD_REQUIRE((prev2 == nullptr || rnorm == nullptr) || rnorm_prev2 != nullptr, "conv3d: prev2 needs its voxel norms");
     OVD_REQUIRE((prev1 == nullptr || rnorm == nullptr) || rnorm_prev1 != nullptr, "conv3d: prev1 needs its voxel norms");
-    return ovd_impl_conv3d_cl(x, prev2, prev1, rnorm, rnorm_prev2, rnorm_prev1, gamma, silu, nullptr, w_split, bias, resid,
+    return ovd_impl_conv3d_cl(x, prev2, prev1, nullptr, nullptr, nullptr, rnorm, rnorm_prev2, rnorm_prev1, gamma, silu,
+                              nullptr, w_split, bias, resid,
                               out, T, H, W, Cin, Cout, KT, KH, KW, stride_t, stride_hw, pad_t, pad_hw, upsample2,
                               time_interleave, ST(stream));
+}
+
+int ovd_vae_act_split(const float* x, const float* gamma, int silu, uint16_t* out, int64_t nvox, int C, void* stream) {
+    NONNULL(x); NONNULL(out);
+    OVD_REQUIRE(nvox >= 0, "act_split: negative voxel count");
+    return ovd_impl_act_split(x, gamma, silu, out, nvox, C, ST(stream));
+}
+
+int ovd_vae_conv3d_ps_f32(const uint16_t* x_split, const uint16_t* prev2_split, const uint16_t* prev1_split,
+                          const uint16_t* w_split, const float* bias, const float* resid, float* out, int T, int H, int W,
+                          int Cin, int Cout, int KT, int KH, int KW, int pad_t, int pad_hw, void* stream) {
+    NONNULL(x_split); NONNULL(w_split); NONNULL(out);
+    return ovd_impl_conv3d_cl(nullptr, nullptr, nullptr, x_split, prev2_split, prev1_split, nullptr, nullptr, nullptr,
+                              nullptr, 0, nullptr, w_split, bias, resid, out, T, H, W, Cin, Cout, KT, KH, KW, 1, 1, pad_t,
+                              pad_hw, 0, 0, ST(stream));
 }
 
 int ovd_vae_voxel_rnorm(const float* x, float* out, int64_t nvox, int C, void* stream) {

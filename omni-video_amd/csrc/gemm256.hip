@@ -338,9 +338,12 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
 
 // True when the shape fits this kernel (the caller falls back to the 128 x 128 kernel otherwise).
 bool ovd_gemm256_applicable(long lda, long ldw, int M, int N, int K) {
-    // one workgroup per CU: worth it from about two rounds of 256 x 256 tiles over the 256 CUs
+    // one workgroup per CU.  From half a round of 256 x 256 tiles the deep pipeline beats the 128 x 128 kernel: at
+    // M = 10 140 (240 tiles) 1 220 against 868 TFLOP/s for N = K = 1536 and 1 469 against 1 037 for K = 8960
     const long tiles = (long)ceil_div(M, TM) * (N / TN);
-    return N % TN == 0 && K % KT == 0 && K >= 2 * KT && M >= 2 * TM && tiles >= 512 &&
+    static std::atomic<int> min_tiles_cache{INT32_MIN};
+    const int min_tiles = ovd_env_int(min_tiles_cache, "OVD_GEMM256_MIN_TILES", 128);      // tuning aid
+    return N % TN == 0 && K % KT == 0 && K >= 2 * KT && M >= 2 * TM && tiles >= min_tiles &&
            (long)M * lda * 2 < (1L << 32) && (long)N * ldw * 2 < (1L << 32);
 }
 

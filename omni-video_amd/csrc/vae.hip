@@ -32,6 +32,8 @@ struct ConvArgs {
     const float* rn; const float* rn_prev2; const float* rn_prev1;   // per-voxel 1/||x|| (or null)
     const float* gamma; const float* w; const float* bias; const float* resid; float* out;
     const uint16_t* ws;                  // weights already split (ovd_vae_split_weights), or null
+    const uint16_t* xs; const uint16_t* prev2s; const uint16_t* prev1s;   // input already activated and split
+                                         // (ovd_vae_act_split): [voxel][chunk][32 hi | 32 lo]; x / prev* are then null
     int T, H, W, Cin, Cout, To, Ho, Wo;
     int KT, KH, KW, st, s, pt, ph;       // kernel, temporal stride, spatial stride, paddings
     int ups, til, silu, TW;              // input 2x upsample, time-interleaved output, SiLU, tile width
@@ -317,6 +319,333 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Producer / consumer form of the 3x3 stride-1 convolutions (split-bf16 products, pre-split weights): the same
+// arithmetic and the same LDS images as conv3d_cl_kernel<NB, true>, with the two halves of its work given to
+// different waves so that they overlap instead of alternating.
+//   * 8 consumer waves own 32 output voxels each of a 16 x 16 patch (256 voxels x 32*NB channels per workgroup):
+//     per tap they read their operand fragments from LDS and issue the NB*6 MFMAs - nothing else.
+//   * 4 producer waves do what conv3d_cl_kernel does between its barriers: they fetch the halo patch of the NEXT
+//     (time tap, 32-channel chunk) group from the activation tensor, apply the voxel norm / gamma / SiLU, split into
+//     bf16 hi | lo and write it to the other halo buffer, a few voxels per tap; and they copy the weight slice of
+//     the tap after next into a ring of three slots.  Every global load is issued one tap before its value is
+//     written to LDS, so a producer never waits for memory inside a tap.
+// One barrier per tap joins the two sides: after barrier j the slot of tap j and (first tap of a group) the
+// group's halo are complete, and the slot of tap j - 1 and the previous group's halo buffer are free.
+// A group whose frame is temporal zero padding is skipped (as in conv3d_cl_kernel).
+// timing-only ablations of the producers (builds under build_variants/; results are wrong when set)
+#ifndef WS_ABL_NO_WEIGHTS
+#define WS_ABL_NO_WEIGHTS 0
+#endif
+#ifndef WS_ABL_NO_HALO
+#define WS_ABL_NO_HALO 0
+#endif
+#ifndef WS_ABL_RAW_HALO
+#define WS_ABL_RAW_HALO 0
+#endif
+constexpr int WS_T = 16;              // patch edge
+constexpr int WS_CONS = 8, WS_PROD = 4;
+constexpr int WS_HIT = 11;            // halo batches of 32 voxels per producer pass: up to 352 voxels (18 x 18 = 324)
+
+// Barrier between the taps: this wave's LDS traffic has retired, then s_barrier.  (A __syncthreads() also waits
+// for every global load the wave has in flight - the producers' fetches for later taps - and would put the
+// memory latency back into every tap.)
+__device__ __forceinline__ void ws_tap_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int NB, bool PRE>
+__global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_w = (a.Wo + WS_T - 1) / WS_T, tiles_h = (a.Ho + WS_T - 1) / WS_T;
+    int bid = blockIdx.x;
+    const int tw_i = bid % tiles_w; bid /= tiles_w;
+    const int th_i = bid % tiles_h;
+    const int to = bid / tiles_h;
+    const int h0 = th_i * WS_T, w0 = tw_i * WS_T;
+    const int n0 = blockIdx.y * 32 * NB;
+    int hs0, ws0, HR, WR;
+    if (a.ups) {
+        hs0 = (h0 - 1) >> 1; ws0 = (w0 - 1) >> 1;
+        HR = ((h0 + WS_T) >> 1) - hs0 + 1; WR = ((w0 + WS_T) >> 1) - ws0 + 1;
+    } else {
+        hs0 = h0 - a.ph; ws0 = w0 - a.ph;
+        HR = WS_T - 1 + a.KH; WR = WS_T - 1 + a.KW;
+    }
+    const int nvox = HR * WR;
+    const int halo_stride = WS_HIT * 32 * LDV;                      // floats per halo buffer (every producer batch has its rows)
+    float* const wt = lds + 2 * halo_stride;                        // 3 x [32*NB][LDV]
+    constexpr int WSLOT = 32 * NB * LDV;
+    const int nchunk = (a.Cin + 31) >> 5;
+    const long frame_elems = (long)a.H * a.W * a.Cin;
+    const long frame_vox = (long)a.H * a.W;
+
+    // The time taps whose frame exists: frames before the first of the video are zero padding and contribute
+    // nothing.  Source frames ascend with kt and a missing one is always the earliest, so the taps that exist are
+    // the last `nact` of the KT.
+    // PRE: the input is the pre-split image; fp then points at its 128-byte voxel-chunk rows (as float*)
+    auto frame = [&](int kt, const float*& fp, const float*& rp) __attribute__((always_inline)) {
+        const int ts = to * a.st + kt - a.pt;
+        if (PRE) {
+            rp = nullptr;
+            if (ts >= 0) fp = reinterpret_cast<const float*>(a.xs + ts * frame_vox * nchunk * 64);
+            else fp = reinterpret_cast<const float*>(ts == -1 ? a.prev1s : a.prev2s);
+            return;
+        }
+        if (ts >= 0) { fp = a.x + ts * frame_elems; rp = a.rn ? a.rn + ts * frame_vox : nullptr; }
+        else if (ts == -1) { fp = a.prev1; rp = a.rn_prev1; }
+        else { fp = a.prev2; rp = a.rn_prev2; }
+    };
+    int nact = 0;
+    for (int kt = 0; kt < a.KT; ++kt) {
+        const float* fp; const float* rp;
+        frame(kt, fp, rp);
+        nact += fp != nullptr ? 1 : 0;
+    }
+    const int kt_first = a.KT - nact;
+    const int G = nact * nchunk;                  // groups; 9 taps each
+    const int ntaps = 9;
+
+    if (wave >= WS_CONS) {
+        // ------------------------------------------------------------------ producers
+        // Every load below is unconditional and every address valid (indices clamped, invalid values replaced
+        // by zero after the load, never by a branch around it): with straight-line code the compiler can count
+        // the loads in flight and waits only for the one a store needs (a load inside a branch makes it wait for
+        // all of them, which would put the memory latency back into every tap).
+        const int ptid = tid - 64 * WS_CONS;
+        const int hv0 = ptid >> 3, hj = ptid & 7;
+        int hpix[WS_HIT];           // source pixel of halo voxel hv0 + 32 * it; -1: outside the frame (zeros)
+#pragma unroll
+        for (int it = 0; it < WS_HIT; ++it) {
+            const int v = min(hv0 + 32 * it, nvox - 1);         // rows beyond the patch repeat its last voxel (never read)
+            const int hr = v / WR, wc_ = v - hr * WR;
+            const int hs = hs0 + hr, ws = ws0 + wc_;
+            hpix[it] = (hs >= 0 && hs < a.H && ws >= 0 && ws < a.W) ? hs * a.W + ws : -1;
+        }
+        int wrow[NB];               // rows beyond Cout repeat the last one: their products land in columns that are not stored
+#pragma unroll
+        for (int i = 0; i < NB; ++i) wrow[i] = min(n0 + hv0 + 32 * i, a.Cout - 1) * nchunk * 64 + 8 * hj;
+        // group g -> (frame, voxel norms, time tap, chunk); evaluated once per group, not per use
+        struct Grp { const float* fp; const float* rp; int kt, cc, ci; bool cok; };
+        auto grp = [&](int g) __attribute__((always_inline)) {
+            Grp r;
+            const int ga = g / nchunk;
+            r.cc = g - ga * nchunk;
+            r.kt = kt_first + ga;
+            frame(r.kt, r.fp, r.rp);
+            if (r.rp == nullptr) r.rp = r.fp;                   // no voxel norms: any readable address
+            r.cok = r.cc * 32 + 4 * hj < a.Cin;
+            r.ci = min(r.cc * 32 + 4 * hj, a.Cin - 4);
+            return r;
+        };
+        // (a register set is a struct of named members, not an array: indexed arrays of float4 ended up in scratch
+        // memory here, and scratch accesses share the counter of the global loads)
+        struct WSet { float4 v0, v1, v2, v3; };
+        auto w_load = [&](const Grp& q, int tap) __attribute__((always_inline)) {
+            WSet v;
+            v.v1 = v.v2 = v.v3 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint16_t* base = a.ws + ((long)(q.kt * ntaps + tap) * a.Cout * nchunk + q.cc) * 64;
+            v.v0 = *reinterpret_cast<const float4*>(base + wrow[0]);
+            if (NB > 1) v.v1 = *reinterpret_cast<const float4*>(base + wrow[NB > 1 ? 1 : 0]);
+            if (NB > 2) v.v2 = *reinterpret_cast<const float4*>(base + wrow[NB > 2 ? 2 : 0]);
+            if (NB > 3) v.v3 = *reinterpret_cast<const float4*>(base + wrow[NB > 3 ? 3 : 0]);
+            return v;
+        };
+        auto w_store = [&](int slot, const WSet v) __attribute__((always_inline)) {
+            char* dst = reinterpret_cast<char*>(wt + slot * WSLOT + hv0 * LDV) + 16 * hj;
+            *reinterpret_cast<float4*>(dst) = v.v0;
+            if (NB > 1) *reinterpret_cast<float4*>(dst + 32 * LDV * 4) = v.v1;
+            if (NB > 2) *reinterpret_cast<float4*>(dst + 64 * LDV * 4) = v.v2;
+            if (NB > 3) *reinterpret_cast<float4*>(dst + 96 * LDV * 4) = v.v3;
+        };
+        auto h_load = [&](const Grp& q, int it, float4& val, float& rn) __attribute__((always_inline)) {
+            const int pix = max(hpix[it], 0);
+            if (PRE) {      // 16 raw bytes of the voxel's 128-byte row of this chunk
+                val = *reinterpret_cast<const float4*>(q.fp + ((long)pix * nchunk + q.cc) * 32 + 4 * hj);
+                rn = 0.f;
+                return;
+            }
+            val = *reinterpret_cast<const float4*>(q.fp + (long)pix * a.Cin + q.ci);
+            rn = q.rp[pix];
+        };
+        auto g_load = [&](const Grp& q) __attribute__((always_inline)) {
+            if (PRE) return make_float4(1.f, 1.f, 1.f, 1.f);
+            return *reinterpret_cast<const float4*>((a.gamma ? a.gamma : q.fp) + q.ci);
+        };
+        const bool has_norm = a.gamma != nullptr, has_silu = a.silu != 0;
+        auto h_store = [&](const Grp& q, int buf, int it, float4 x, float rn, const float4& gm) __attribute__((always_inline)) {
+            if (PRE || WS_ABL_RAW_HALO) {
+                if (hpix[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                float* dst = lds + buf * halo_stride + (hv0 + 32 * it) * LDV;
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(dst) + 16 * hj) = x;
+                return;
+            }
+            if (has_norm) {
+                const float r = rn * a.norm_scale;
+                x.x = x.x * r * gm.x; x.y = x.y * r * gm.y; x.z = x.z * r * gm.z; x.w = x.w * r * gm.w;
+            }
+            if (has_silu) { x.x = silu_f(x.x); x.y = silu_f(x.y); x.z = silu_f(x.z); x.w = silu_f(x.w); }
+            if (!(hpix[it] >= 0 && q.cok)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            float* dst = lds + buf * halo_stride + (hv0 + 32 * it) * LDV;
+            store_split4(reinterpret_cast<char*>(dst) + 8 * hj, x);
+        };
+
+        // Prologue: the first group's halo and the slices of its first two taps, fetched and written at once;
+        // the slices of taps 2..4 are put in flight.  In the loop every value is fetched three or more taps (a few
+        // microseconds) before it is written to LDS: slice of tap j + 5 at tap j (three register sets, written at
+        // tap j + 3 into the slot tap j + 2 has left); the next group's halo two batches per tap in taps 0..5, each
+        // written three taps later (six batches in registers at a time).  The last group fetches and writes its
+        // own data once more in place of a next group's (into the buffer nobody reads any more).
+        WSet wreg0, wreg1, wreg2;
+        Grp cur = grp(0);
+        constexpr int HRING = 6;
+        float4 hv[HRING];
+        float hn[HRING];
+        {
+            const float4 gm = g_load(cur);
+#pragma unroll
+            for (int i0 = 0; i0 < WS_HIT; i0 += HRING) {
+#pragma unroll
+                for (int it = i0; it < i0 + HRING && it < WS_HIT; ++it) h_load(cur, it, hv[it - i0], hn[it - i0]);
+#pragma unroll
+                for (int it = i0; it < i0 + HRING && it < WS_HIT; ++it) h_store(cur, 0, it, hv[it - i0], hn[it - i0], gm);
+            }
+            wreg0 = w_load(cur, 0);
+            w_store(0, wreg0);
+            wreg1 = w_load(cur, 1);
+            w_store(1, wreg1);
+            wreg2 = w_load(cur, 2);
+            wreg0 = w_load(cur, 3);
+            wreg1 = w_load(cur, 4);
+        }
+        for (int g = 0; g < G; ++g) {
+            const Grp nxt = grp(min(g + 1, G - 1));
+            const float4 gm = g_load(nxt);
+            const int nbuf = (g + 1) & 1;
+            // tap T: the slice of tap T + 2 leaves register set WSET for its slot, the slice of tap T + 5 is fetched
+            // into the set; halo batches fetched at tap T - 3 are written, two more are fetched (taps 0..5)
+#define WS_PRODUCER_TAP(T, WSET)                                                                           \
+            {                                                                                              \
+                ws_tap_barrier();                                                                          \
+                if (!WS_ABL_NO_WEIGHTS) {                                                                  \
+                    w_store(((T) + 2) % 3, WSET);                                                          \
+                    if ((T) + 5 < 9) WSET = w_load(cur, (T) + 5);                                          \
+                    else WSET = w_load(nxt, (T) + 5 - 9);                                                  \
+                }                                                                                          \
+                if (WS_ABL_NO_HALO) {                                                                      \
+                } else if ((T) >= 3) {                                                                            \
+                    _Pragma("unroll") for (int it = 2 * ((T) - 3); it < 2 * ((T) - 3) + 2 && it < WS_HIT; ++it) \
+                        h_store(nxt, nbuf, it, hv[it % HRING], hn[it % HRING], gm);                        \
+                }                                                                                          \
+                if (!WS_ABL_NO_HALO && (T) <= 5) {                                                         \
+                    _Pragma("unroll") for (int it = 2 * (T); it < 2 * (T) + 2 && it < WS_HIT; ++it)        \
+                        h_load(nxt, it, hv[it % HRING], hn[it % HRING]);                                   \
+                }                                                                                          \
+            }
+            WS_PRODUCER_TAP(0, wreg2) WS_PRODUCER_TAP(1, wreg0) WS_PRODUCER_TAP(2, wreg1)
+            WS_PRODUCER_TAP(3, wreg2) WS_PRODUCER_TAP(4, wreg0) WS_PRODUCER_TAP(5, wreg1)
+            WS_PRODUCER_TAP(6, wreg2) WS_PRODUCER_TAP(7, wreg0) WS_PRODUCER_TAP(8, wreg1)
+#undef WS_PRODUCER_TAP
+            cur = nxt;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int iv = wave * 32 + (lane & 31);
+    const int dh = iv >> 4, dw = iv & (WS_T - 1);
+    const int kq = lane >> 5;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[nb][j] = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float* halo = lds + (g & 1) * halo_stride;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            ws_tap_barrier();
+            const int kh = t / 3, kw = t % 3;
+            int hsrc, wsrc;
+            if (a.ups) { hsrc = ((h0 + dh + kh - 1) >> 1) - hs0; wsrc = ((w0 + dw + kw - 1) >> 1) - ws0; }
+            else { hsrc = dh + kh; wsrc = dw + kw; }
+            const char* ac = reinterpret_cast<const char*>(halo + (hsrc * WR + wsrc) * LDV + 4 * kq);
+            const char* bc = reinterpret_cast<const char*>(wt + (t % 3) * WSLOT + (lane & 31) * LDV + 4 * kq);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ac + 32 * ks);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ac + 64 + 32 * ks);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bc + nb * 32 * LDV * 4 + 32 * ks);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bc + nb * 32 * LDV * 4 + 64 + 32 * ks);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    MFMA_DRAIN();
+    const int C_out_row = a.Cout;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int co = n0 + nb * 32 + (lane & 31);
+        if (co >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
+            const int ho = h0 + (ov >> 4), wo = w0 + (ov & (WS_T - 1));
+            if (ho >= a.Ho || wo >= a.Wo) continue;
+            const long o = (((long)to * a.Ho + ho) * a.Wo + wo) * C_out_row + co;
+            float v = acc[nb][reg] + bv;
+            if (a.resid) v += a.resid[o];
+            a.out[o] = v;
+        }
+    }
+}
+
+// x fp32 [nvox][C] -> the convolution's LDS image of its input, written once instead of by every workgroup that
+// stages the voxel: out uint16 [nvox][C/32][32 hi | 32 lo], value = act(x) split into bf16 hi + bf16 lo, with
+// act = RMS_norm (F.normalize over the channels * sqrt(C) * gamma; gamma null = off) followed by SiLU (silu != 0):
+// RMS_norm.forward + nn.SiLU in front of the convolutions of ResidualBlock and of the heads (vae2_1.py:50-53,
+// 193-197).  LPV lanes share a voxel (NI float4 each), as in voxel_rnorm_kernel.  C % 32 == 0.
+template <int LPV, int NI>
+__global__ void __launch_bounds__(256) act_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        int silu, uint16_t* __restrict__ out, long nvox, int C,
+                                                        float norm_scale) {
+    const int lane = threadIdx.x & 63, sub = lane % LPV;
+    const long v = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPV) + lane / LPV;
+    const bool live = v < nvox;
+    const float4* p = reinterpret_cast<const float4*>(x + (live ? v : 0) * C);
+    float4 val[NI], gm[NI];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        val[i] = p[sub + i * LPV];
+        gm[i] = gamma ? reinterpret_cast<const float4*>(gamma)[sub + i * LPV] : make_float4(1.f, 1.f, 1.f, 1.f);
+        ss += val[i].x * val[i].x + val[i].y * val[i].y + val[i].z * val[i].z + val[i].w * val[i].w;
+    }
+#pragma unroll
+    for (int o = LPV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float r = gamma ? (1.0f / fmaxf(sqrtf(ss), 1e-12f)) * norm_scale : 1.f;
+    if (!live) return;
+    const int nchunk = C >> 5;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        float4 y = val[i];
+        if (gamma) { y.x = y.x * r * gm[i].x; y.y = y.y * r * gm[i].y; y.z = y.z * r * gm[i].z; y.w = y.w * r * gm[i].w; }
+        if (silu) { y.x = silu_f(y.x); y.y = silu_f(y.y); y.z = silu_f(y.z); y.w = silu_f(y.w); }
+        const int q = sub + i * LPV;                 // float4 index inside the voxel: chunk q / 8, piece q % 8
+        store_split4(reinterpret_cast<char*>(out + (v * nchunk + (q >> 3)) * 64) + 8 * (q & 7), y);
+    }
+}
+
 // 1 / max(||x_v||_2, 1e-12) per voxel (F.normalize's denominator, vae2_1.py:50-53).  LPV lanes share
 // a voxel (LPV = the largest power of two dividing C/4, so every lane loads the same number of
 // float4s: 8 lanes x 3 for C = 96, 16 x 3 for 192, 32 x 3 for 384) and a wave covers 64/LPV voxels.
@@ -416,7 +745,8 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ s
 
 }  // namespace
 
-int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, const float* rn, const float* rn_prev2,
+int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, const uint16_t* xs,
+                       const uint16_t* prev2s, const uint16_t* prev1s, const float* rn, const float* rn_prev2,
                        const float* rn_prev1, const float* gamma, int silu, const float* w, const uint16_t* w_split,
                        const float* bias,
                        const float* resid, float* out, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW,
@@ -437,6 +767,7 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
     const int To = (T + pad_t - KT) / stride_t + 1;
     OVD_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "conv3d: output would be empty");
     ConvArgs a;
+    a.xs = xs; a.prev2s = prev2s; a.prev1s = prev1s;
     a.x = x; a.prev2 = prev2; a.prev1 = prev1; a.rn = rn; a.rn_prev2 = rn_prev2; a.rn_prev1 = rn_prev1;
     a.gamma = gamma; a.w = w; a.ws = w_split; a.bias = bias; a.resid = resid; a.out = out;
     a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.To = To; a.Ho = Ho; a.Wo = Wo;
@@ -487,6 +818,31 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
     } break;
     OVD_REQUIRE(w != nullptr || (w_split != nullptr && !exact),
                 "conv3d: the exact-fp32 path (OVD_VAE_EXACT_FP32) needs the fp32 weights");
+    // 3x3 stride-1 convolutions on pre-split weights: the producer / consumer kernel (OVD_VAE_WS=0 disables)
+    static std::atomic<int> ws_cache{INT32_MIN};
+    const bool pre = xs != nullptr;
+    const bool ws_ok = !exact && w_split != nullptr && KH == 3 && stride_hw == 1 && stride_t == 1 && !time_interleave;
+    OVD_REQUIRE(!pre || (ws_ok && Cin % 32 == 0 && !upsample2),
+                "conv3d: a pre-split input needs split weights, a 3x3 stride-1 kernel, Cin %% 32 == 0 and the split-bf16 path");
+    if (ws_ok && (pre || ovd_env_int(ws_cache, "OVD_VAE_WS", 1) != 0)) {
+        const int t16 = ((a.Wo + WS_T - 1) / WS_T) * ((a.Ho + WS_T - 1) / WS_T) * To;
+        int nbw = nb == 4 ? 2 : nb;          // (128 channels per workgroup would spill the producers' registers)
+        if (nbw > 1 && (long)t16 * ceil_div(Cout, 32 * nbw) < (long)cus) nbw = 1;
+        const size_t lds_ws = (size_t)(2 * WS_HIT * 32 + 3 * 32 * nbw) * LDV * sizeof(float);
+        dim3 gridw(t16, ceil_div(Cout, 32 * nbw)), blkw(64 * (WS_CONS + WS_PROD));
+#define WS_CASE(NBV, PREV)                                                                                   \
+    case NBV: {                                                                                              \
+        static OvdLdsLimit lim;                                                                              \
+        if (!lim.ensure(reinterpret_cast<const void*>(&conv3d_ws_kernel<NBV, PREV>), lds_ws))                \
+            OVD_FAIL("conv3d: cannot reserve %zu bytes of LDS", lds_ws);                                     \
+        hipLaunchKernelGGL((conv3d_ws_kernel<NBV, PREV>), gridw, blkw, lds_ws, st, a);                       \
+    } break;
+        if (pre) { switch (nbw) { WS_CASE(1, true) WS_CASE(2, true) WS_CASE(3, true) } }
+        else { switch (nbw) { WS_CASE(1, false) WS_CASE(2, false) WS_CASE(3, false) } }
+#undef WS_CASE
+        OVD_CHECK_LAUNCH("conv3d_ws");
+        return 0;
+    }
     if (exact) {
         a.ws = nullptr;
         switch (nb) { CONV_CASE(1, false) CONV_CASE(2, false) CONV_CASE(3, false) CONV_CASE(4, false) }
@@ -513,6 +869,26 @@ int ovd_impl_voxel_rnorm(const float* x, float* out, long nvox, int C, hipStream
     else RN_CASE(1);
 #undef RN_CASE
     OVD_CHECK_LAUNCH("voxel_rnorm");
+    return 0;
+}
+
+int ovd_impl_act_split(const float* x, const float* gamma, int silu, uint16_t* out, long nvox, int C, hipStream_t st) {
+    OVD_REQUIRE(C > 0 && C % 32 == 0, "act_split: C=%d must be a multiple of 32", C);
+    if (nvox == 0) return 0;
+    const int q = C / 4;
+    const float ns = sqrtf((float)C);
+#define AS_CASE(L, N)                                                                                          \
+    hipLaunchKernelGGL((act_split_kernel<L, N>), dim3(ceil_div(nvox, 4 * (64 / L))), dim3(256), 0, st, x, gamma, silu, \
+                       out, nvox, C, ns)
+    // LPV lanes x NI float4 = C / 4 (NI <= 6 values in registers per lane)
+    if (q % 32 == 0 && q / 32 <= 6) { switch (q / 32) { case 1: AS_CASE(32, 1); break; case 2: AS_CASE(32, 2); break;
+        case 3: AS_CASE(32, 3); break; case 4: AS_CASE(32, 4); break; case 5: AS_CASE(32, 5); break; default: AS_CASE(32, 6); } }
+    else if (q % 16 == 0 && q / 16 <= 3) { switch (q / 16) { case 1: AS_CASE(16, 1); break; case 2: AS_CASE(16, 2); break;
+        default: AS_CASE(16, 3); } }
+    else if (q / 8 <= 3) { switch (q / 8) { case 1: AS_CASE(8, 1); break; case 2: AS_CASE(8, 2); break; default: AS_CASE(8, 3); } }
+    else OVD_FAIL("act_split: unsupported channel count C=%d", C);
+#undef AS_CASE
+    OVD_CHECK_LAUNCH("act_split");
     return 0;
 }
 

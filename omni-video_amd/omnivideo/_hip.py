@@ -56,6 +56,8 @@ SIGNATURES = {
     "ovd_vae_conv3d_f32": [_p] * 7 + [_i] + [_p] * 4 + [_i] * 14 + [_p],
     "ovd_vae_conv3d_sw_f32": [_p] * 7 + [_i] + [_p] * 4 + [_i] * 14 + [_p],
     "ovd_vae_split_weights": [_p, _p, _l, _i, _p],
+    "ovd_vae_act_split": [_p, _p, _i, _p, _l, _i, _p],
+    "ovd_vae_conv3d_ps_f32": [_p] * 7 + [_i] * 10 + [_p],
     "ovd_vae_voxel_rnorm": [_p, _p, _l, _i, _p],
     "ovd_vae_to_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _p],
     "ovd_vae_from_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
@@ -540,6 +542,42 @@ def vae_conv3d(x, w, bias, kernel, prev2=None, prev1=None, rnorm=None, rnorm_pre
           w.data.data_ptr() if split else _f32c(w),
           _f32c(bias, True), _f32c(resid, True), _f32c(out), T, H, W, Cin, Cout, KT, KH, KW, stride_t, stride_hw,
           pad_t, pad_hw, int(upsample2), int(time_interleave), _stream())
+    return out
+
+
+def vae_act_split(x, gamma=None, silu=False):
+    """x fp32 [T,H,W,C] (C % 32 == 0) -> int16 [T,H,W,C/32,64]: SiLU(RMS_norm(x)) (each optional) as the
+    split-bf16 image the convolution kernel stages (ovd_vae_act_split)."""
+    C = x.shape[-1]
+    if C % 32:
+        raise ValueError("vae_act_split: C must be a multiple of 32")
+    out = torch.empty(tuple(x.shape[:-1]) + (C // 32, 64), dtype=torch.int16, device=x.device)
+    _call("ovd_vae_act_split", _f32c(x), _f32c(gamma, True), int(silu), out.data_ptr(), x.numel() // C, C, _stream())
+    return out
+
+
+def vae_conv3d_ps(xs, w, bias, kernel, prev2=None, prev1=None, resid=None, pad_t=0, pad_hw=0, out=None):
+    """The 3x3 stride-1 convolution on a pre-activated, pre-split input (vae_act_split): xs int16
+    [T,H,W,Cin/32,64], w a SplitWeight [KT*9, Cout, Cin]; prev1 / prev2 the [H,W,Cin/32,64] frames at time -1 / -2."""
+    T, H, W, nch, _ = xs.shape
+    KT, KH, KW = kernel
+    taps, Cout, Cin = w.shape
+    if not isinstance(w, SplitWeight) or taps != KT * KH * KW or Cin != nch * 32 or xs.dtype != torch.int16 \
+            or not xs.is_contiguous():
+        raise ValueError("conv3d_ps: needs a contiguous int16 split input and matching SplitWeight weights")
+    for p in (prev1, prev2):
+        if p is not None and (tuple(p.shape) != (H, W, nch, 64) or p.dtype != torch.int16 or not p.is_contiguous()):
+            raise ValueError("conv3d_ps: previous-chunk frame has the wrong shape")
+    shape = (T + pad_t - KT + 1, H + 2 * pad_hw - KH + 1, W + 2 * pad_hw - KW + 1, Cout)
+    if out is None:
+        out = torch.empty(shape, dtype=F32, device=xs.device)
+    elif tuple(out.shape) != shape:
+        raise ValueError(f"conv3d_ps: out has shape {tuple(out.shape)}, expected {shape}")
+    if resid is not None and tuple(resid.shape) != shape:
+        raise ValueError("conv3d_ps: residual shape mismatch")
+    _call("ovd_vae_conv3d_ps_f32", xs.data_ptr(), None if prev2 is None else prev2.data_ptr(),
+          None if prev1 is None else prev1.data_ptr(), w.data.data_ptr(), _f32c(bias, True), _f32c(resid, True), _f32c(out),
+          T, H, W, Cin, Cout, KT, KH, KW, pad_t, pad_hw, _stream())
     return out
 
 

@@ -247,9 +247,20 @@ class _Runner:
         w, b, k = self.weight(conv)
         if self.shard is not None and k[1] > 1:
             self.shard.refresh(x)
-        rn = H.vae_voxel_rnorm(x) if norm is not None else None
-        gamma = norm.gamma.detach().reshape(-1).to(F32).contiguous() if norm is not None else None
         c = self.ctx.setdefault(name, _Ctx()) if name is not None else None
+        gamma = norm.gamma.detach().reshape(-1).to(F32).contiguous() if norm is not None else None
+        if norm is not None and isinstance(w, H.SplitWeight) and k[1:] == (3, 3) and x.shape[-1] % 32 == 0 \
+                and kw.get("pad_hw", 0) == 1 and not (set(kw) - {"pad_t", "pad_hw"}):
+            # Normalised + activated convolutions (the bulk of the FLOPs): norm, SiLU and the split into bf16
+            # hi | lo happen once per layer here, and the kernel's input staging is then pure copies.  The
+            # temporal context is kept in that form too.
+            xs = H.vae_act_split(x, gamma, silu)
+            y = H.vae_conv3d_ps(xs, w, b, k, prev2=None if c is None else c.p2, prev1=None if c is None else c.p1,
+                                resid=resid, pad_t=kw.get("pad_t", 0), pad_hw=1)
+            if c is not None:
+                c.push(xs, None)
+            return y
+        rn = H.vae_voxel_rnorm(x) if norm is not None else None
         p1 = p2 = r1 = r2 = None
         if c is not None:
             p1, p2, r1, r2 = c.p1, c.p2, c.r1, c.r2

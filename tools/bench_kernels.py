@@ -201,6 +201,17 @@ if __name__ == "__main__":
             line.append(f"N{N}K{K}e{epi} {2.0 * M * N * K / 1e9 / t:.0f}")
             del a, w, out
         print(os.environ.get("OVD_LIB_PATH", "default").split("/")[-1], " | ".join(line), flush=True)
+    if "gemmsp" in args.what:       # the Linear shapes of a sequence-parallel rank of the 1.3B model (2 and 4 ranks)
+        for M in (20280, 10140):
+            line = []
+            for (N, K, epi) in ((4608, 1536, 0), (1536, 1536, 0), (8960, 1536, 1), (1536, 8960, 0)):
+                a = torch.randn(M, K, device="cuda").to(BF16)
+                w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF16)
+                b = torch.randn(N, device="cuda").to(BF16)
+                out = torch.zeros(M, N, device="cuda", dtype=BF16)
+                t = min(timeit(lambda: H.gemm(a, w, out, b, epi), iters=20) for _ in range(3))
+                line.append(f"N{N}K{K}e{epi} {2.0 * M * N * K / 1e9 / t:.0f}")
+            print(f"M{M} min_tiles={os.environ.get('OVD_GEMM256_MIN_TILES', 'default')}", " | ".join(line), flush=True)
     if "twostream" in args.what:    # does a second stream's kernel fill the partly empty last round of tiles?
         C, F, L = 1536, 8960, 20280
         def layer_ops(M, tag):
