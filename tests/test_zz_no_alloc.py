@@ -60,3 +60,40 @@ def test_static_workspace_attention_rejects_bad_arguments():
         H.flash_attn(q, k, v, out, k_len=0, static_workspace=True)
     with pytest.raises(ValueError, match="either"):
         H.flash_attn(q, k, v, out, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"), static_workspace=True)
+
+
+def test_static_workspace_rejects_a_split_beyond_the_array_on_a_larger_device():
+    """The built-in array covers every split the plan produces on up to 256 compute units.  On a part with more
+    (planned here for 304 through OVD_DEVICE_CUS, in a child process: the count is read once) a shape whose last
+    round splits 17 query blocks per XCD needs more than the array holds: the allocation-free entry refuses it with
+    the figures, the caller-workspace entry takes it."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from omnivideo import _hip as H\n"
+        "B, L, N = 1, 14080, 8\n"
+        "g = torch.Generator(device='cuda').manual_seed(5)\n"
+        "q, k, v = (torch.randn(B, L, N, 128, device='cuda', generator=g).to(torch.bfloat16) for _ in range(3))\n"
+        "out = torch.empty_like(q)\n"
+        "need = H.flash_attn_workspace_bytes(B, L, N, L)\n"
+        "assert need > 34603008, need\n"
+        "try:\n"
+        "    H.flash_attn(q, k, v, out, static_workspace=True)\n"
+        "except RuntimeError as err:\n"
+        "    assert 'built-in array holds 34603008' in str(err) and str(need) in str(err), str(err)\n"
+        "else:\n"
+        "    raise AssertionError('accepted a split the array cannot hold')\n"
+        "ws = torch.empty(need, dtype=torch.uint8, device='cuda')\n"
+        "H.flash_attn(q, k, v, out, workspace=ws)\n"
+        "ref = torch.empty_like(q)\n"
+        "H.flash_attn(q, k, v, ref)\n"
+        "torch.cuda.synchronize()\n"
+        "assert (out.float() - ref.float()).abs().max().item() < 2e-2\n"
+        "print('ok')\n"
+    ) % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omni-video_amd")
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OVD_DEVICE_CUS="304"), capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-500:] + res.stderr[-2000:]
