@@ -172,6 +172,45 @@ def test_one_block_full_width_full_length_vs_oracle():
     check_rel("1.3B block, full grid, vs bf16 oracle", rel, 2e-4)      # observed 6.2e-5
 
 
+def test_v2v_mixed_context_full_size_block_vs_oracle():
+    """The video-to-video workload's own condition at its real size (BASELINE configuration 3): 700 VLM rows + 550
+    text rows + the 5 070 visual-adapter tokens of a 13 x 60 x 104 source latent + the four delimiter tokens = 6 324
+    rows, truncated at max_context_len 6 272 (reference unified_model.py:247-272) - so no key is zero padding and
+    cross-attention reads all 6 272 keys.  Condition builder (VLM projection, visual adapter, tight concatenation,
+    truncation) and one 1.3B-width block on the full 20 280-token grid through the model's own forward, against the
+    oracle's unified forward in its bf16 flow (about 30 s of CPU)."""
+    from omnivideo.modules.unified_model import UnifiedWanWithMixedConditionModel
+    text_len = 6272
+    cfg = syn.dit_config("1.3B", num_layers=1, text_len=text_len)
+    sd = syn.make_unified_state_dict(cfg, 0)
+    sp = syn.make_special_tokens(cfg, 0)
+    m = UnifiedWanWithMixedConditionModel(wan_config=dict(cfg), vlm_in_dim=cfg["vlm_in_dim"],
+                                          use_visual_context_adapter=True,
+                                          visual_context_adapter_patch_size=cfg["visual_patch_size"],
+                                          max_context_len=text_len, eps=cfg["eps"], skip_init=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(BF16).cuda().eval()
+    lat = syn.randn("v2v.lat", (16, 13, 60, 104), 1).to(BF16)
+    text = syn.randn("v2v.text", (550, cfg["text_dim"]), 1).to(BF16)
+    ar = syn.randn("v2v.ar", (700, cfg["vlm_in_dim"]), 1).to(BF16)
+    visual = syn.randn("v2v.visual", (1, 16, 13, 60, 104), 1)
+    spd = {k: v.cuda().to(BF16) for k, v in sp.items()}
+    with torch.no_grad():
+        mixed = m.build_mixed_context(1, [text.cuda()], [ar.cuda()], visual.cuda(), spd)[0]
+        assert tuple(mixed.shape) == (text_len, cfg["text_dim"])           # 6 324 rows truncated
+        out = m([lat.cuda()], t=torch.tensor([640], device="cuda"), context=[text.cuda()], ar_vision_input=[ar.cuda()],
+                visual_emb=visual.cuda(), special_token_dict=spd, seq_len=L)[0]
+        torch.cuda.synchronize()
+        eng = m.wan_model.engine()
+        assert m.wan_model._ctx_cache.k_len == text_len                     # nothing folded: every key is real
+        sdb = O.round_weights_bf16(sd)
+        ref = O.unified_forward(lat.float(), 640, sdb, cfg, L, "bf16", text=text.float(), ar_vision=ar.float(),
+                                visual=visual, special=sp)
+    assert eng is not None and torch.isfinite(out).all()
+    rel = float((out.cpu() - ref).norm() / ref.norm())
+    check_rel("V2V mixed context (6 272 keys) + 1.3B block, full grid, vs bf16 oracle", rel, 6e-4)
+
+
 def test_vae_decode_full_size_causality():
     """49-frame 480p decode with the full-width VAE (random weights): finite, clamped, and causal -
     decoding the first 5 latent frames alone gives exactly the first 17 frames of the full video
