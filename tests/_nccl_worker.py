@@ -27,6 +27,15 @@ def main():
     send = torch.randn(1, 3, 2, 5, 128, device="cuda", generator=g).to(torch.bfloat16)
     recv = torch.zeros_like(send)
     comm.all_to_all(recv, send)
+    # split-phase form (what the overlapped sequence-parallel forward issues): queued, other work, then waited for
+    recv2, recv3 = torch.zeros_like(send), torch.zeros_like(send)
+    comm.all_to_all_start(recv2, send, ("qkv", 0, 0))
+    comm.all_to_all_start(recv3, send.flip(1).contiguous(), ("qkv", 1, 0))
+    busy = (send.float() @ send.float().transpose(-1, -2)).sum()
+    comm.wait(("qkv", 0, 0))
+    comm.wait(("qkv", 1, 0))
+    torch.cuda.synchronize()
+    assert torch.equal(recv2, send) and torch.equal(recv3, send.flip(1)) and torch.isfinite(busy)
     t = torch.randn(2, 16, 3, 8, 12, device="cuda", generator=g)
     t0 = t.clone()
     comm.all_reduce_sum(t)

@@ -208,7 +208,7 @@ def test_v2v_mixed_context_full_size_block_vs_oracle():
                                 visual=visual, special=sp)
     assert eng is not None and torch.isfinite(out).all()
     rel = float((out.cpu() - ref).norm() / ref.norm())
-    check_rel("V2V mixed context (6 272 keys) + 1.3B block, full grid, vs bf16 oracle", rel, 6e-4)
+    check_rel("V2V mixed context (6 272 keys) + 1.3B block, full grid, vs bf16 oracle", rel, 2.5e-4)      # observed 8.4e-5
 
 
 def test_vae_decode_full_size_causality():
