@@ -389,11 +389,13 @@ int ovd_vae_conv3d_sw_f32(const float* x, const float* prev2, const float* prev1
  * ResidualBlock and of the encoder / decoder heads (vae2_1.py:50-53,193-197,311-314,416-419).  C % 32 == 0.
  * ovd_vae_conv3d_ps_f32: the 3x3 (KT = 1 or 3) stride-1 convolution of ovd_vae_conv3d_sw_f32 on such an image
  * (x_split [T][H][W][Cin/32][64]; prev*_split the [H][W][Cin/32][64] frames at time -2 / -1, NULL = zeros):
- * same products, same accumulation, bit-identical results; the kernel's staging is then pure copies. */
+ * same products, same accumulation, bit-identical results; the kernel's staging is then pure copies.  upsample2 != 0:
+ * the convolution runs on the nearest-neighbour 2x spatial upsampling of the image (output [T][2H][2W][Cout]; the
+ * Upsample + Conv2d pair of Resample, vae2_1.py:72-84), as in ovd_vae_conv3d_sw_f32. */
 int ovd_vae_act_split(const float* x, const float* gamma, int silu, uint16_t* out, int64_t nvox, int C, void* stream);
 int ovd_vae_conv3d_ps_f32(const uint16_t* x_split, const uint16_t* prev2_split, const uint16_t* prev1_split,
                           const uint16_t* w_split, const float* bias, const float* resid, float* out, int T, int H, int W,
-                          int Cin, int Cout, int KT, int KH, int KW, int pad_t, int pad_hw, void* stream);
+                          int Cin, int Cout, int KT, int KH, int KW, int pad_t, int pad_hw, int upsample2, void* stream);
 
 /* out[v] = 1 / max(||x[v,:]||_2, 1e-12) for nvox voxels of C channels: the denominator of
  * F.normalize in RMS_norm.forward (vae2_1.py:50-53). */

@@ -403,11 +403,11 @@ int ovd_vae_act_split(const float* x, const float* gamma, int silu, uint16_t* ou
 
 int ovd_vae_conv3d_ps_f32(const uint16_t* x_split, const uint16_t* prev2_split, const uint16_t* prev1_split,
                           const uint16_t* w_split, const float* bias, const float* resid, float* out, int T, int H, int W,
-                          int Cin, int Cout, int KT, int KH, int KW, int pad_t, int pad_hw, void* stream) {
+                          int Cin, int Cout, int KT, int KH, int KW, int pad_t, int pad_hw, int upsample2, void* stream) {
     NONNULL(x_split); NONNULL(w_split); NONNULL(out);
     return ovd_impl_conv3d_cl(nullptr, nullptr, nullptr, x_split, prev2_split, prev1_split, nullptr, nullptr, nullptr,
                               nullptr, 0, nullptr, w_split, bias, resid, out, T, H, W, Cin, Cout, KT, KH, KW, 1, 1, pad_t,
-                              pad_hw, 0, 0, ST(stream));
+                              pad_hw, upsample2, 0, ST(stream));
 }
 
 int ovd_vae_voxel_rnorm(const float* x, float* out, int64_t nvox, int C, void* stream) {

@@ -297,25 +297,35 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
     // hazard padding does not reach across the nested-loop exit (the last register came back
     // stale).  Pad explicitly.
     MFMA_DRAIN();
-    // epilogue: D row = voxel (reg&3)+8*(reg>>2)+4*kq of this wave's 32, column = lane&31 = channel
+    // epilogue: D row = voxel (reg&3)+8*(reg>>2)+4*kq of this wave's 32, column = lane&31 = channel.  The residual
+    // values of a 32-channel block are all fetched before its first store (out and resid may be one buffer as far as
+    // the compiler knows, so a load placed after a store would wait for it).
     const int C_out_row = a.til ? a.Cout / 2 : a.Cout;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int co = n0 + nb * 32 + (lane & 31);
-        if (co >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.f;
+        const bool cok = co < a.Cout;
+        const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
         int frame = to, cch = co;
         if (a.til) { frame = 2 * to + co / C_out_row; cch = co % C_out_row; }
+        long off[16];
+        float rv[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
             const int ho = h0 + (ov >> tw_shift), wo = w0 + (ov & (TW - 1));
-            if (ho >= a.Ho || wo >= a.Wo) continue;
-            const long o = (((long)frame * a.Ho + ho) * a.Wo + wo) * C_out_row + cch;
-            float v = acc[nb][reg] + bv;
-            if (a.resid) v += a.resid[o];
-            a.out[o] = v;
+            off[reg] = (cok && ho < a.Ho && wo < a.Wo) ? (((long)frame * a.Ho + ho) * a.Wo + wo) * C_out_row + cch : -1;
         }
+        if (a.resid) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) rv[reg] = a.resid[max(off[reg], 0L)];
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) rv[reg] = 0.f;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            if (off[reg] >= 0) a.out[off[reg]] = acc[nb][reg] + bv + rv[reg];
     }
 }
 
@@ -343,6 +353,12 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
 #ifndef WS_ABL_RAW_HALO
 #define WS_ABL_RAW_HALO 0
 #endif
+#ifndef WS_ABL_NO_READS
+#define WS_ABL_NO_READS 0
+#endif
+#ifndef WS_ABL_NO_BARRIER
+#define WS_ABL_NO_BARRIER 0
+#endif
 constexpr int WS_T = 16;              // patch edge
 constexpr int WS_CONS = 8, WS_PROD = 4;
 constexpr int WS_HIT = 11;            // halo batches of 32 voxels per producer pass: up to 352 voxels (18 x 18 = 324)
@@ -351,9 +367,21 @@ constexpr int WS_HIT = 11;            // halo batches of 32 voxels per producer 
 // for every global load the wave has in flight - the producers' fetches for later taps - and would put the
 // memory latency back into every tap.)
 __device__ __forceinline__ void ws_tap_barrier() {
+    if (WS_ABL_NO_BARRIER) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+
+// 16 bytes through a buffer descriptor: wave-uniform base and scalar offset, 32-bit per-lane offset (no 64-bit address
+// arithmetic per load); an offset beyond the descriptor's size reads zeros.
+typedef unsigned int ws_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ws_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const ws_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
 template <int NB, bool PRE>
@@ -412,23 +440,15 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
 
     if (wave >= WS_CONS) {
         // ------------------------------------------------------------------ producers
+        // Two roles, two waves each: waves 8-9 copy weight slices, waves 10-11 stage the halo.  A wave's loads return
+        // in order as far as its counter can tell, so a wave that fetched both would hold every (L2-resident) weight
+        // slice behind the HBM latency of the halo voxels fetched before it.
         // Every load below is unconditional and every address valid (indices clamped, invalid values replaced
         // by zero after the load, never by a branch around it): with straight-line code the compiler can count
         // the loads in flight and waits only for the one a store needs (a load inside a branch makes it wait for
         // all of them, which would put the memory latency back into every tap).
-        const int ptid = tid - 64 * WS_CONS;
-        const int hv0 = ptid >> 3, hj = ptid & 7;
-        int hpix[WS_HIT];           // source pixel of halo voxel hv0 + 32 * it; -1: outside the frame (zeros)
-#pragma unroll
-        for (int it = 0; it < WS_HIT; ++it) {
-            const int v = min(hv0 + 32 * it, nvox - 1);         // rows beyond the patch repeat its last voxel (never read)
-            const int hr = v / WR, wc_ = v - hr * WR;
-            const int hs = hs0 + hr, ws = ws0 + wc_;
-            hpix[it] = (hs >= 0 && hs < a.H && ws >= 0 && ws < a.W) ? hs * a.W + ws : -1;
-        }
-        int wrow[NB];               // rows beyond Cout repeat the last one: their products land in columns that are not stored
-#pragma unroll
-        for (int i = 0; i < NB; ++i) wrow[i] = min(n0 + hv0 + 32 * i, a.Cout - 1) * nchunk * 64 + 8 * hj;
+        const int rtid = tid - 64 * WS_CONS - (wave >= WS_CONS + 2 ? 128 : 0);      // 0..127 inside the role
+        const int hv0 = rtid >> 3, hj = rtid & 7;
         // group g -> (frame, voxel norms, time tap, chunk); evaluated once per group, not per use
         struct Grp { const float* fp; const float* rp; int kt, cc, ci; bool cok; };
         auto grp = [&](int g) __attribute__((always_inline)) {
@@ -442,33 +462,94 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
             r.ci = min(r.cc * 32 + 4 * hj, a.Cin - 4);
             return r;
         };
-        // (a register set is a struct of named members, not an array: indexed arrays of float4 ended up in scratch
-        // memory here, and scratch accesses share the counter of the global loads)
-        struct WSet { float4 v0, v1, v2, v3; };
-        auto w_load = [&](const Grp& q, int tap) __attribute__((always_inline)) {
-            WSet v;
-            v.v1 = v.v2 = v.v3 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const uint16_t* base = a.ws + ((long)(q.kt * ntaps + tap) * a.Cout * nchunk + q.cc) * 64;
-            v.v0 = *reinterpret_cast<const float4*>(base + wrow[0]);
-            if (NB > 1) v.v1 = *reinterpret_cast<const float4*>(base + wrow[NB > 1 ? 1 : 0]);
-            if (NB > 2) v.v2 = *reinterpret_cast<const float4*>(base + wrow[NB > 2 ? 2 : 0]);
-            if (NB > 3) v.v3 = *reinterpret_cast<const float4*>(base + wrow[NB > 3 ? 3 : 0]);
-            return v;
-        };
-        auto w_store = [&](int slot, const WSet v) __attribute__((always_inline)) {
-            char* dst = reinterpret_cast<char*>(wt + slot * WSLOT + hv0 * LDV) + 16 * hj;
-            *reinterpret_cast<float4*>(dst) = v.v0;
-            if (NB > 1) *reinterpret_cast<float4*>(dst + 32 * LDV * 4) = v.v1;
-            if (NB > 2) *reinterpret_cast<float4*>(dst + 64 * LDV * 4) = v.v2;
-            if (NB > 3) *reinterpret_cast<float4*>(dst + 96 * LDV * 4) = v.v3;
-        };
+        if (wave < WS_CONS + 2) {
+            // ---- weight slices: 32*NB rows x 8 pieces of 16 bytes over 128 lanes = 2*NB pieces per lane.  The slice
+            // of tap j + 5 is fetched at tap j into one of three register sets and written at tap j + 3 into the slot
+            // tap j + 2 has left.  (A register set is a struct of named members returned by value: indexed arrays of
+            // float4 ended up in scratch memory here, and scratch accesses share the counter of the global loads.)
+            // per-lane BYTE offsets as 32-bit values; the slice's offset travels in a scalar register
+            unsigned wrow[2 * NB];  // rows beyond Cout repeat the last one: their products land in columns that are not stored
+#pragma unroll
+            for (int i = 0; i < 2 * NB; ++i) wrow[i] = (unsigned)(min(n0 + hv0 + 16 * i, a.Cout - 1) * nchunk * 64 + 8 * hj) * 2u;
+            const __amdgpu_buffer_rsrc_t wres = ws_rsrc(a.ws, (unsigned)(a.KT * ntaps * a.Cout * nchunk) * 128u);
+            struct WSet { float4 v0, v1, v2, v3, v4, v5; };
+            auto w_load = [&](const Grp& q, int tap) __attribute__((always_inline)) {
+                WSet v;
+                const unsigned so = (unsigned)((q.kt * ntaps + tap) * a.Cout * nchunk + q.cc) * 128u;
+                v.v0 = ws_buf_load(wres, wrow[0], so);
+                v.v1 = ws_buf_load(wres, wrow[1], so);
+                v.v2 = v.v3 = v.v4 = v.v5 = v.v0;
+                if (NB > 1) {
+                    v.v2 = ws_buf_load(wres, wrow[NB > 1 ? 2 : 0], so);
+                    v.v3 = ws_buf_load(wres, wrow[NB > 1 ? 3 : 0], so);
+                }
+                if (NB > 2) {
+                    v.v4 = ws_buf_load(wres, wrow[NB > 2 ? 4 : 0], so);
+                    v.v5 = ws_buf_load(wres, wrow[NB > 2 ? 5 : 0], so);
+                }
+                return v;
+            };
+            auto w_store = [&](int slot, const WSet v) __attribute__((always_inline)) {
+                char* dst = reinterpret_cast<char*>(wt + slot * WSLOT + hv0 * LDV) + 16 * hj;
+                *reinterpret_cast<float4*>(dst) = v.v0;
+                *reinterpret_cast<float4*>(dst + 16 * LDV * 4) = v.v1;
+                if (NB > 1) {
+                    *reinterpret_cast<float4*>(dst + 32 * LDV * 4) = v.v2;
+                    *reinterpret_cast<float4*>(dst + 48 * LDV * 4) = v.v3;
+                }
+                if (NB > 2) {
+                    *reinterpret_cast<float4*>(dst + 64 * LDV * 4) = v.v4;
+                    *reinterpret_cast<float4*>(dst + 80 * LDV * 4) = v.v5;
+                }
+            };
+            Grp cur = grp(0);
+            WSet wreg0 = w_load(cur, 0), wreg1 = w_load(cur, 1), wreg2;
+            w_store(0, wreg0);
+            w_store(1, wreg1);
+            wreg2 = w_load(cur, 2);
+            wreg0 = w_load(cur, 3);
+            wreg1 = w_load(cur, 4);
+            for (int g = 0; g < G; ++g) {
+                const Grp nxt = grp(min(g + 1, G - 1));       // the last group fetches its own slices again (never read)
+#define WS_WEIGHT_TAP(T, WSET)                                                                             \
+                {                                                                                          \
+                    ws_tap_barrier();                                                                      \
+                    if (!WS_ABL_NO_WEIGHTS) {                                                              \
+                        w_store(((T) + 2) % 3, WSET);                                                      \
+                        if ((T) + 5 < 9) WSET = w_load(cur, (T) + 5);                                      \
+                        else WSET = w_load(nxt, (T) + 5 - 9);                                              \
+                    }                                                                                      \
+                }
+                WS_WEIGHT_TAP(0, wreg2) WS_WEIGHT_TAP(1, wreg0) WS_WEIGHT_TAP(2, wreg1)
+                WS_WEIGHT_TAP(3, wreg2) WS_WEIGHT_TAP(4, wreg0) WS_WEIGHT_TAP(5, wreg1)
+                WS_WEIGHT_TAP(6, wreg2) WS_WEIGHT_TAP(7, wreg0) WS_WEIGHT_TAP(8, wreg1)
+#undef WS_WEIGHT_TAP
+                cur = nxt;
+            }
+            return;
+        }
+        // ---- halo: batches of 16 voxels (8 lanes per voxel row of 128 bytes); the next group's halo is fetched four
+        // batches per tap in taps 0..5 and each batch is written three taps after its fetch (twelve in registers).
+        constexpr int HB = 2 * WS_HIT;      // batches of 16 voxels
+        int hpix[HB];                       // source pixel of halo voxel hv0 + 16 * it; -1: outside the frame (zeros)
+        unsigned hoff[PRE ? HB : 1];        // PRE: byte offset of this lane's 16 bytes inside the frame's chunk-0 image
+#pragma unroll
+        for (int it = 0; it < HB; ++it) {
+            const int v = min(hv0 + 16 * it, nvox - 1);         // rows beyond the patch repeat its last voxel (never read)
+            const int hr = v / WR, wc_ = v - hr * WR;
+            const int hs = hs0 + hr, ws = ws0 + wc_;
+            hpix[it] = (hs >= 0 && hs < a.H && ws >= 0 && ws < a.W) ? hs * a.W + ws : -1;
+            // outside the frame: an offset beyond the descriptor, which reads zeros
+            if (PRE) hoff[it] = hpix[it] >= 0 ? (unsigned)hpix[it] * (unsigned)(nchunk * 128) + 16u * hj : 0x80000000u;
+        }
+        const unsigned frame_bytes = (unsigned)(a.H * a.W * nchunk) * 128u;
         auto h_load = [&](const Grp& q, int it, float4& val, float& rn) __attribute__((always_inline)) {
-            const int pix = max(hpix[it], 0);
             if (PRE) {      // 16 raw bytes of the voxel's 128-byte row of this chunk
-                val = *reinterpret_cast<const float4*>(q.fp + ((long)pix * nchunk + q.cc) * 32 + 4 * hj);
+                val = ws_buf_load(ws_rsrc(q.fp, frame_bytes), hoff[it], (unsigned)q.cc * 128u);
                 rn = 0.f;
                 return;
             }
+            const int pix = max(hpix[it], 0);
             val = *reinterpret_cast<const float4*>(q.fp + (long)pix * a.Cin + q.ci);
             rn = q.rp[pix];
         };
@@ -478,9 +559,9 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
         };
         const bool has_norm = a.gamma != nullptr, has_silu = a.silu != 0;
         auto h_store = [&](const Grp& q, int buf, int it, float4 x, float rn, const float4& gm) __attribute__((always_inline)) {
+            float* dst = lds + buf * halo_stride + (hv0 + 16 * it) * LDV;
             if (PRE || WS_ABL_RAW_HALO) {
-                if (hpix[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
-                float* dst = lds + buf * halo_stride + (hv0 + 32 * it) * LDV;
+                if (!PRE && hpix[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(reinterpret_cast<char*>(dst) + 16 * hj) = x;
                 return;
             }
@@ -490,66 +571,39 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
             }
             if (has_silu) { x.x = silu_f(x.x); x.y = silu_f(x.y); x.z = silu_f(x.z); x.w = silu_f(x.w); }
             if (!(hpix[it] >= 0 && q.cok)) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            float* dst = lds + buf * halo_stride + (hv0 + 32 * it) * LDV;
             store_split4(reinterpret_cast<char*>(dst) + 8 * hj, x);
         };
-
-        // Prologue: the first group's halo and the slices of its first two taps, fetched and written at once;
-        // the slices of taps 2..4 are put in flight.  In the loop every value is fetched three or more taps (a few
-        // microseconds) before it is written to LDS: slice of tap j + 5 at tap j (three register sets, written at
-        // tap j + 3 into the slot tap j + 2 has left); the next group's halo two batches per tap in taps 0..5, each
-        // written three taps later (six batches in registers at a time).  The last group fetches and writes its
-        // own data once more in place of a next group's (into the buffer nobody reads any more).
-        WSet wreg0, wreg1, wreg2;
-        Grp cur = grp(0);
-        constexpr int HRING = 6;
+        constexpr int HRING = 12, HPT = 4;            // batches in registers / fetched per tap
         float4 hv[HRING];
         float hn[HRING];
-        {
+        Grp cur = grp(0);
+        {       // prologue: the first group's halo, fetched and written at once
             const float4 gm = g_load(cur);
 #pragma unroll
-            for (int i0 = 0; i0 < WS_HIT; i0 += HRING) {
+            for (int i0 = 0; i0 < HB; i0 += HRING) {
 #pragma unroll
-                for (int it = i0; it < i0 + HRING && it < WS_HIT; ++it) h_load(cur, it, hv[it - i0], hn[it - i0]);
+                for (int it = i0; it < i0 + HRING && it < HB; ++it) h_load(cur, it, hv[it - i0], hn[it - i0]);
 #pragma unroll
-                for (int it = i0; it < i0 + HRING && it < WS_HIT; ++it) h_store(cur, 0, it, hv[it - i0], hn[it - i0], gm);
+                for (int it = i0; it < i0 + HRING && it < HB; ++it) h_store(cur, 0, it, hv[it - i0], hn[it - i0], gm);
             }
-            wreg0 = w_load(cur, 0);
-            w_store(0, wreg0);
-            wreg1 = w_load(cur, 1);
-            w_store(1, wreg1);
-            wreg2 = w_load(cur, 2);
-            wreg0 = w_load(cur, 3);
-            wreg1 = w_load(cur, 4);
         }
         for (int g = 0; g < G; ++g) {
-            const Grp nxt = grp(min(g + 1, G - 1));
+            const Grp nxt = grp(min(g + 1, G - 1));           // the last group stages its own halo again (never read)
             const float4 gm = g_load(nxt);
             const int nbuf = (g + 1) & 1;
-            // tap T: the slice of tap T + 2 leaves register set WSET for its slot, the slice of tap T + 5 is fetched
-            // into the set; halo batches fetched at tap T - 3 are written, two more are fetched (taps 0..5)
-#define WS_PRODUCER_TAP(T, WSET)                                                                           \
-            {                                                                                              \
-                ws_tap_barrier();                                                                          \
-                if (!WS_ABL_NO_WEIGHTS) {                                                                  \
-                    w_store(((T) + 2) % 3, WSET);                                                          \
-                    if ((T) + 5 < 9) WSET = w_load(cur, (T) + 5);                                          \
-                    else WSET = w_load(nxt, (T) + 5 - 9);                                                  \
-                }                                                                                          \
-                if (WS_ABL_NO_HALO) {                                                                      \
-                } else if ((T) >= 3) {                                                                            \
-                    _Pragma("unroll") for (int it = 2 * ((T) - 3); it < 2 * ((T) - 3) + 2 && it < WS_HIT; ++it) \
-                        h_store(nxt, nbuf, it, hv[it % HRING], hn[it % HRING], gm);                        \
-                }                                                                                          \
-                if (!WS_ABL_NO_HALO && (T) <= 5) {                                                         \
-                    _Pragma("unroll") for (int it = 2 * (T); it < 2 * (T) + 2 && it < WS_HIT; ++it)        \
-                        h_load(nxt, it, hv[it % HRING], hn[it % HRING]);                                   \
-                }                                                                                          \
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                ws_tap_barrier();
+                if (!WS_ABL_NO_HALO && t >= 3) {       // batches fetched at tap t - 3
+#pragma unroll
+                    for (int it = HPT * (t - 3); it < HPT * (t - 3) + HPT && it < HB; ++it)
+                        h_store(nxt, nbuf, it, hv[it % HRING], hn[it % HRING], gm);
+                }
+                if (!WS_ABL_NO_HALO && t <= 5) {
+#pragma unroll
+                    for (int it = HPT * t; it < HPT * t + HPT && it < HB; ++it) h_load(nxt, it, hv[it % HRING], hn[it % HRING]);
+                }
             }
-            WS_PRODUCER_TAP(0, wreg2) WS_PRODUCER_TAP(1, wreg0) WS_PRODUCER_TAP(2, wreg1)
-            WS_PRODUCER_TAP(3, wreg2) WS_PRODUCER_TAP(4, wreg0) WS_PRODUCER_TAP(5, wreg1)
-            WS_PRODUCER_TAP(6, wreg2) WS_PRODUCER_TAP(7, wreg0) WS_PRODUCER_TAP(8, wreg1)
-#undef WS_PRODUCER_TAP
             cur = nxt;
         }
         return;
@@ -575,6 +629,14 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
             else { hsrc = dh + kh; wsrc = dw + kw; }
             const char* ac = reinterpret_cast<const char*>(halo + (hsrc * WR + wsrc) * LDV + 4 * kq);
             const char* bc = reinterpret_cast<const char*>(wt + (t % 3) * WSLOT + (lane & 31) * LDV + 4 * kq);
+            if (WS_ABL_NO_READS) {      // timing only: operands from two reads per tap instead of sixteen
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ac), bh = *reinterpret_cast<const bf16x8*>(bc);
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nb], 0, 0, 0);
+                continue;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ac + 32 * ks);
@@ -591,22 +653,32 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
         }
     }
     MFMA_DRAIN();
-    const int C_out_row = a.Cout;
+    // Epilogue: the residual values of a 32-channel block are all fetched before the first store (out and resid may be
+    // one buffer as far as the compiler knows, so a load placed after a store would wait for it: sixteen memory
+    // round trips in a row per block instead of one).
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int co = n0 + nb * 32 + (lane & 31);
-        if (co >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.f;
+        const bool cok = co < a.Cout;
+        const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+        long off[16];
+        float rv[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
             const int ho = h0 + (ov >> 4), wo = w0 + (ov & (WS_T - 1));
-            if (ho >= a.Ho || wo >= a.Wo) continue;
-            const long o = (((long)to * a.Ho + ho) * a.Wo + wo) * C_out_row + co;
-            float v = acc[nb][reg] + bv;
-            if (a.resid) v += a.resid[o];
-            a.out[o] = v;
+            off[reg] = (cok && ho < a.Ho && wo < a.Wo) ? (((long)to * a.Ho + ho) * a.Wo + wo) * a.Cout + co : -1;
         }
+        if (a.resid) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) rv[reg] = a.resid[max(off[reg], 0L)];
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) rv[reg] = 0.f;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            if (off[reg] >= 0) a.out[off[reg]] = acc[nb][reg] + bv + rv[reg];
     }
 }
 
@@ -821,8 +893,12 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
     // 3x3 stride-1 convolutions on pre-split weights: the producer / consumer kernel (OVD_VAE_WS=0 disables)
     static std::atomic<int> ws_cache{INT32_MIN};
     const bool pre = xs != nullptr;
-    const bool ws_ok = !exact && w_split != nullptr && KH == 3 && stride_hw == 1 && stride_t == 1 && !time_interleave;
-    OVD_REQUIRE(!pre || (ws_ok && Cin % 32 == 0 && !upsample2),
+    // (the kernel addresses the split weights, and a pre-split frame, with 32-bit byte offsets)
+    const long nchunk_l = (Cin + 31) / 32;
+    const bool ws_ok = !exact && w_split != nullptr && KH == 3 && stride_hw == 1 && stride_t == 1 && !time_interleave &&
+                       (long)KT * 9 * Cout * nchunk_l * 128 < (1L << 31);
+    OVD_REQUIRE(xs == nullptr || (long)H * W * nchunk_l * 128 < (1L << 31), "conv3d: a pre-split frame must stay below 2 GiB");
+    OVD_REQUIRE(!pre || (ws_ok && Cin % 32 == 0),
                 "conv3d: a pre-split input needs split weights, a 3x3 stride-1 kernel, Cin %% 32 == 0 and the split-bf16 path");
     if (ws_ok && (pre || ovd_env_int(ws_cache, "OVD_VAE_WS", 1) != 0)) {
         const int t16 = ((a.Wo + WS_T - 1) / WS_T) * ((a.Ho + WS_T - 1) / WS_T) * To;

@@ -57,7 +57,7 @@ SIGNATURES = {
     "ovd_vae_conv3d_sw_f32": [_p] * 7 + [_i] + [_p] * 4 + [_i] * 14 + [_p],
     "ovd_vae_split_weights": [_p, _p, _l, _i, _p],
     "ovd_vae_act_split": [_p, _p, _i, _p, _l, _i, _p],
-    "ovd_vae_conv3d_ps_f32": [_p] * 7 + [_i] * 10 + [_p],
+    "ovd_vae_conv3d_ps_f32": [_p] * 7 + [_i] * 11 + [_p],
     "ovd_vae_voxel_rnorm": [_p, _p, _l, _i, _p],
     "ovd_vae_to_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _p],
     "ovd_vae_from_channels_last": [_p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
@@ -556,9 +556,10 @@ def vae_act_split(x, gamma=None, silu=False):
     return out
 
 
-def vae_conv3d_ps(xs, w, bias, kernel, prev2=None, prev1=None, resid=None, pad_t=0, pad_hw=0, out=None):
+def vae_conv3d_ps(xs, w, bias, kernel, prev2=None, prev1=None, resid=None, pad_t=0, pad_hw=0, upsample2=False, out=None):
     """The 3x3 stride-1 convolution on a pre-activated, pre-split input (vae_act_split): xs int16
-    [T,H,W,Cin/32,64], w a SplitWeight [KT*9, Cout, Cin]; prev1 / prev2 the [H,W,Cin/32,64] frames at time -1 / -2."""
+    [T,H,W,Cin/32,64], w a SplitWeight [KT*9, Cout, Cin]; prev1 / prev2 the [H,W,Cin/32,64] frames at time -1 / -2;
+    upsample2: convolve the nearest-neighbour 2x spatial upsampling of the image."""
     T, H, W, nch, _ = xs.shape
     KT, KH, KW = kernel
     taps, Cout, Cin = w.shape
@@ -568,7 +569,8 @@ def vae_conv3d_ps(xs, w, bias, kernel, prev2=None, prev1=None, resid=None, pad_t
     for p in (prev1, prev2):
         if p is not None and (tuple(p.shape) != (H, W, nch, 64) or p.dtype != torch.int16 or not p.is_contiguous()):
             raise ValueError("conv3d_ps: previous-chunk frame has the wrong shape")
-    shape = (T + pad_t - KT + 1, H + 2 * pad_hw - KH + 1, W + 2 * pad_hw - KW + 1, Cout)
+    Hin, Win = (2 * H, 2 * W) if upsample2 else (H, W)
+    shape = (T + pad_t - KT + 1, Hin + 2 * pad_hw - KH + 1, Win + 2 * pad_hw - KW + 1, Cout)
     if out is None:
         out = torch.empty(shape, dtype=F32, device=xs.device)
     elif tuple(out.shape) != shape:
@@ -577,7 +579,7 @@ def vae_conv3d_ps(xs, w, bias, kernel, prev2=None, prev1=None, resid=None, pad_t
         raise ValueError("conv3d_ps: residual shape mismatch")
     _call("ovd_vae_conv3d_ps_f32", xs.data_ptr(), None if prev2 is None else prev2.data_ptr(),
           None if prev1 is None else prev1.data_ptr(), w.data.data_ptr(), _f32c(bias, True), _f32c(resid, True), _f32c(out),
-          T, H, W, Cin, Cout, KT, KH, KW, pad_t, pad_hw, _stream())
+          T, H, W, Cin, Cout, KT, KH, KW, pad_t, pad_hw, int(upsample2), _stream())
     return out
 
 

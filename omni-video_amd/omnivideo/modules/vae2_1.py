@@ -329,10 +329,14 @@ class _Runner:
                 x = y
         w, b, k = self.weight(rs.resample[1])
         if self.shard is not None:
-            # [rows + 2] -> 2 rows + 4: the outermost row on each side is dropped, leaving one extra row
             self.shard.refresh(x)
-            return H.vae_conv3d(x, w, b, k, pad_hw=1, upsample2=True)[:, 1:-1].contiguous()
-        return H.vae_conv3d(x, w, b, k, pad_hw=1, upsample2=True)
+        if isinstance(w, H.SplitWeight) and x.shape[-1] % 32 == 0:
+            # the source image split into bf16 hi | lo once (a quarter of the output's voxels), staged by pure copies
+            y = H.vae_conv3d_ps(H.vae_act_split(x), w, b, k, pad_hw=1, upsample2=True)
+        else:
+            y = H.vae_conv3d(x, w, b, k, pad_hw=1, upsample2=True)
+        # sharded: [rows + 2] -> 2 rows + 4: the outermost row on each side is dropped, leaving one extra row
+        return y[:, 1:-1].contiguous() if self.shard is not None else y
 
     def downsample(self, x, rs, name):
         """reference Resample.forward, downsample modes (vae2_1.py:137-159)"""

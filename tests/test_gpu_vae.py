@@ -101,6 +101,56 @@ def test_upsample_conv_and_downsample_conv(H, Hh, Ww):
     torch.testing.assert_close(cf(y), ref, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.skipif(EXACT, reason="split weights belong to the split-bf16 path")
+@pytest.mark.parametrize("cin,cout,T,Hh,Ww,nctx", [(32, 32, 3, 9, 17, 2), (64, 96, 1, 8, 16, 1), (96, 96, 2, 33, 18, 2),
+                                                   (96, 3, 2, 10, 33, 0), (128, 160, 1, 4, 6, 2), (16, 128, 2, 5, 7, 2)])
+def test_split_weight_and_presplit_routes(H, cin, cout, T, Hh, Ww, nctx):
+    """The producer / consumer kernel: (a) pre-split weights + fp32 input (norm, SiLU, residual fused) against the
+    reference arithmetic; (b) the pre-activated, pre-split input route, bit-identical to (a).  Patches of 16 x 16 that
+    the frame does not fill, channel counts that are no multiple of the 96 / 64 / 32 a workgroup makes, 0 - 2 context
+    frames."""
+    x = syn.randn("sw.x", (cin, T, Hh, Ww), 6)
+    ctx = syn.randn("sw.ctx", (cin, 2, Hh, Ww), 6)
+    g = 1 + syn.randn("sw.g", (cin,), 6, 0.1)
+    w = syn.uniform("sw.w", (cout, cin, 3, 3, 3), (27 * cin) ** -0.5, 6)
+    b = syn.randn("sw.b", (cout,), 6, 0.1)
+    res = syn.randn("sw.r", (cout, T, Hh, Ww), 6)
+    act = lambda t: F.silu(V.rms_norm(t, g))
+    ref = V.causal_conv(act(x), w, b, act(ctx[:, 2 - nctx:]) if nctx else None) + res
+    wk, k = prep_w(w)
+    sw = H.SplitWeight(wk)
+    xc, cc = cl(x), cl(ctx)
+    rn, rc = H.vae_voxel_rnorm(xc), H.vae_voxel_rnorm(cc)
+    p2, p1 = (cc[0] if nctx == 2 else None), (cc[1] if nctx >= 1 else None)
+    y = H.vae_conv3d(xc, sw, b.cuda(), k, prev2=p2, prev1=p1, rnorm=rn, rnorm_prev2=None if p2 is None else rc[0],
+                     rnorm_prev1=None if p1 is None else rc[1], gamma=g.cuda(), silu=True, resid=cl(res), pad_t=2, pad_hw=1)
+    torch.testing.assert_close(cf(y), ref, rtol=RTOL, atol=ATOL)
+    if cin % 32 == 0:
+        xs, cs = H.vae_act_split(xc, g.cuda(), True), H.vae_act_split(cc, g.cuda(), True)
+        y2 = H.vae_conv3d_ps(xs, sw, b.cuda(), k, prev2=None if p2 is None else cs[0], prev1=None if p1 is None else cs[1],
+                             resid=cl(res), pad_t=2, pad_hw=1)
+        assert torch.equal(y2, y)
+
+
+@pytest.mark.skipif(EXACT, reason="split weights belong to the split-bf16 path")
+@pytest.mark.parametrize("Hh,Ww", [(6, 10), (8, 16), (5, 9), (17, 12)])
+def test_upsample_conv_on_split_routes(H, Hh, Ww):
+    """Resample's Upsample(2x nearest) + Conv2d on pre-split weights, from the fp32 image and from its pre-split form
+    (the route the decoder takes): equal to each other bit for bit and to torch's fp32 result within the path's tolerance."""
+    c = 64
+    x = syn.randn("us.x", (c, 2, Hh, Ww), 3)
+    w = syn.uniform("us.w", (c // 2, c, 3, 3), (9 * c) ** -0.5, 3)
+    b = syn.randn("us.b", (c // 2,), 3, 0.1)
+    up = F.interpolate(x.permute(1, 0, 2, 3), scale_factor=(2.0, 2.0), mode="nearest-exact")
+    ref = F.conv2d(up, w, b, padding=1).permute(1, 0, 2, 3)
+    wk, k = prep_w(w)
+    sw = H.SplitWeight(wk)
+    y = H.vae_conv3d(cl(x), sw, b.cuda(), k, pad_hw=1, upsample2=True)
+    torch.testing.assert_close(cf(y), ref, rtol=RTOL, atol=ATOL)
+    y2 = H.vae_conv3d_ps(H.vae_act_split(cl(x)), sw, b.cuda(), k, pad_hw=1, upsample2=True)
+    assert torch.equal(y2, y)
+
+
 def test_time_convs(H):
     c, T, Hh, Ww = 32, 3, 5, 6
     x = syn.randn("tc.x", (c, T, Hh, Ww), 4)
