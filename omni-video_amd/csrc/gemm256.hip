@@ -102,9 +102,12 @@ __device__ __forceinline__ void quadrant(f32x4 (&acc)[4][8], const bf16x8 (&wf)[
 }
 
 // TAIL 0: steady state, 1: next-to-last K-tile (nothing to stage two tiles ahead), 2: last.
+// bias_lane / bias_q (TAIL 2 only): this lane's bias values are requested in the last K-tile, behind its last counted
+// wait, and land under its remaining two phases.
 template <int TAIL>
 __device__ __forceinline__ void k_tile64(f32x4 (&acc)[4][8], char* smem, int buf, long kb1, long kb2, const Src4& sa,
-                                         const Src4& sw, int lo0, int lo1, int a_rd, int w_rd, int wave) {
+                                         const Src4& sw, int lo0, int lo1, int a_rd, int w_rd, int wave,
+                                         const bf16_t* bias_lane = nullptr, unsigned long long* bias_q = nullptr) {
     const char* cur = smem + buf * PAIR;
     char* own = smem + buf * PAIR + wave * 1024;
     char* oth = smem + (buf ^ 1) * PAIR + wave * 1024;
@@ -134,6 +137,16 @@ __device__ __forceinline__ void k_tile64(f32x4 (&acc)[4][8], char* smem, int buf
     }
     if (TAIL < 2) stage_half<1>(sa, kb1, oth);
     phase_open<TAIL == 2 ? 0 : 8>();
+    if (TAIL == 2 && bias_lane != nullptr) {
+        // Inline assembly, so that the compiler keeps no books on these loads: one it knows to be pending makes it
+        // drain the DMA queue (s_waitcnt vmcnt(0)) wherever its register shuffling touches the destination.  Nothing
+        // else is in flight here (the wait above was vmcnt(0)); the epilogue waits for them itself.
+        asm volatile("global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %4, off offset:32\n\t"
+                     "global_load_dwordx2 %2, %4, off offset:256\n\tglobal_load_dwordx2 %3, %4, off offset:288"
+                     : "=&v"(bias_q[0]), "=&v"(bias_q[1]), "=&v"(bias_q[2]), "=&v"(bias_q[3])
+                     : "v"(bias_lane)
+                     : "memory");
+    }
     quadrant<2, 0>(acc, w1, af);
     phase_close();
     // phase 3
@@ -192,18 +205,7 @@ gemm256_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // bias (and gate) of this lane's 16 output columns, fetched ahead of the first DMA so that the epilogue
-    // does not start with a global-load round trip: n = col0 + (nt >> 1) * 128 + wc * 32 + (nt & 1) * 16 + fq * 4
     const int fr = lane & 15, fq = lane >> 4;
-    uint2 bias_bits[4];
-    float4 gate_v[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = col0 + (nt >> 1) * 128 + wc * 32 + (nt & 1) * 16 + fq * 4;
-        bias_bits[nt] = bias ? *reinterpret_cast<const uint2*>(bias + n) : make_uint2(0u, 0u);
-        if (EPI == EPI_RESID) gate_v[nt] = gate ? *reinterpret_cast<const float4*>(gate + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-    }
-
     char* const wdst = smem + wave * 1024;
     const int nk = K / 64;      // >= 2 (checked on the host)
     stage_half<0>(sw, 0, wdst + PAIR / 2);
@@ -220,20 +222,27 @@ gemm256_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ 
         k_tile64<0>(acc, smem, t & 1, (long)(t + 1) * 128, (long)(t + 2) * 128, sa, sw, lo0, lo1, a_rd, w_rd, wave);
     k_tile64<1>(acc, smem, t & 1, (long)(t + 1) * 128, 0, sa, sw, lo0, lo1, a_rd, w_rd, wave);
     ++t;
-    k_tile64<2>(acc, smem, t & 1, 0, 0, sa, sw, lo0, lo1, a_rd, w_rd, wave);
+    // bias of this lane's 16 output columns: n = col0 + (nt >> 1) * 128 + wc * 32 + (nt & 1) * 16 + fq * 4
+    unsigned long long bias_q[4] = {0ull, 0ull, 0ull, 0ull};
+    k_tile64<2>(acc, smem, t & 1, 0, 0, sa, sw, lo0, lo1, a_rd, w_rd, wave, bias ? bias + col0 + wc * 32 + fq * 4 : nullptr,
+                bias_q);
     if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
+    // the bias values have landed; the registers are operands so that no use of them can be scheduled above the wait
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias_q[0]), "+v"(bias_q[1]), "+v"(bias_q[2]), "+v"(bias_q[3])::"memory");
 
     // epilogue: lane holds out[m][n .. n+3],
     //   m = row0 + (mt >> 2) * 128 + wr * 64 + (mt & 3) * 16 + fr,  n = col0 + (nt >> 1) * 128 + wc * 32 + (nt & 1) * 16 + fq * 4
     float bv[4][4], gv[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        bv[nt][0] = bf2f(bias_bits[nt].x & 0xffff);
-        bv[nt][1] = bf2f(bias_bits[nt].x >> 16);
-        bv[nt][2] = bf2f(bias_bits[nt].y & 0xffff);
-        bv[nt][3] = bf2f(bias_bits[nt].y >> 16);
-        if (EPI == EPI_RESID) {
-            gv[nt][0] = gate_v[nt].x; gv[nt][1] = gate_v[nt].y; gv[nt][2] = gate_v[nt].z; gv[nt][3] = gate_v[nt].w;
+        const uint32_t blo = (uint32_t)bias_q[nt], bhi = (uint32_t)(bias_q[nt] >> 32);
+        bv[nt][0] = bf2f(blo & 0xffff);
+        bv[nt][1] = bf2f(blo >> 16);
+        bv[nt][2] = bf2f(bhi & 0xffff);
+        bv[nt][3] = bf2f(bhi >> 16);
+        if (EPI == EPI_RESID && !wide_store && gate) {      // (the row-wise epilogue fetches the gate in its own layout)
+            const float4 g = *reinterpret_cast<const float4*>(gate + col0 + (nt >> 1) * 128 + wc * 32 + (nt & 1) * 16 + fq * 4);
+            gv[nt][0] = g.x; gv[nt][1] = g.y; gv[nt][2] = g.z; gv[nt][3] = g.w;
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) gv[nt][j] = 1.f;
@@ -244,28 +253,31 @@ gemm256_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ 
         // written in the accumulator layout (8 B per lane), read back 16 B per lane so that 32 lanes store one
         // whole 512-byte row segment.  16-byte chunk c of row r sits at chunk c ^ (r & 15): conflict-free both ways.
         bf16_t* ob = reinterpret_cast<bf16_t*>(out) + (long)row0 * ldo + col0 + (lane & 31) * 8;
+        // both halves are staged before the one barrier (the ring's two buffers are free), and the barrier waits for
+        // this wave's LDS writes only: __syncthreads() would also wait for global stores in flight
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float y[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = acc[nt][mt][j] + bv[nt][j];
+                if (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(round_bf(y[j]));
+                }
+                uint2 o;
+                o.x = pack_bf2(y[0], y[1]);
+                o.y = pack_bf2(y[2], y[3]);
+                const int r = wr * 64 + (mt & 3) * 16 + fr;
+                const int c = (nt >> 1) * 16 + wc * 4 + (nt & 1) * 2 + (fq >> 1);
+                *reinterpret_cast<uint2*>(smem + (mt >> 2) * PAIR + r * 512 + ((c ^ fr) << 4) + (fq & 1) * 8) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            char* img = smem + hf * PAIR;
-#pragma unroll
-            for (int mt = 4 * hf; mt < 4 * hf + 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    float y[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = acc[nt][mt][j] + bv[nt][j];
-                    if (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(round_bf(y[j]));
-                    }
-                    uint2 o;
-                    o.x = pack_bf2(y[0], y[1]);
-                    o.y = pack_bf2(y[2], y[3]);
-                    const int r = wr * 64 + (mt & 3) * 16 + fr;
-                    const int c = (nt >> 1) * 16 + wc * 4 + (nt & 1) * 2 + (fq >> 1);
-                    *reinterpret_cast<uint2*>(img + r * 512 + ((c ^ fr) << 4) + (fq & 1) * 8) = o;
-                }
-            __syncthreads();
+            const char* img = smem + hf * PAIR;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int r = i * 16 + wave * 2 + (lane >> 5);
@@ -276,6 +288,58 @@ gemm256_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ 
                     __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w},
                                                 reinterpret_cast<u32x4*>(ob + (long)(hf * 128 + r) * ldo));
             }
+        }
+    } else if ((EPI == EPI_F32 || EPI == EPI_RESID) && wide_store) {
+        // fp32 output (out = round_bf(acc + bias), or out += gate * that, in place) through LDS as well: the tile is
+        // staged as bf16 - the values are bf16-representable - in the image of the bf16 path, both 128-row halves at
+        // once (the ring is free), and each wave then walks whole rows: 64 lanes x 16 bytes = one contiguous 1 KiB row
+        // segment per load and per store.  In the accumulator layout a wave's load touches sixteen rows with 64 bytes in
+        // each, and the 512 KB a tile reads and writes then take longer than half its products.
+        // The old values of the first PF rows are requested between the staging and its barrier, the later ones PF rows
+        // ahead of their use.
+        float* const orow = reinterpret_cast<float*>(out) + col0 + lane * 4;
+        float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (EPI == EPI_RESID && gate) g4 = *reinterpret_cast<const float4*>(gate + col0 + lane * 4);
+        constexpr int PF = 12;
+        float4 xo[PF];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                uint2 o;
+                o.x = pack_bf2(acc[nt][mt][0] + bv[nt][0], acc[nt][mt][1] + bv[nt][1]);
+                o.y = pack_bf2(acc[nt][mt][2] + bv[nt][2], acc[nt][mt][3] + bv[nt][3]);
+                const int r = wr * 64 + (mt & 3) * 16 + fr;
+                const int c = (nt >> 1) * 16 + wc * 4 + (nt & 1) * 2 + (fq >> 1);
+                *reinterpret_cast<uint2*>(smem + (mt >> 2) * PAIR + r * 512 + ((c ^ fr) << 4) + (fq & 1) * 8) = o;
+            }
+        asm volatile("" ::: "memory");      // (the accumulators are dead from here: room for the rows in flight)
+        if (EPI == EPI_RESID) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                xo[i] = *reinterpret_cast<const float4*>(orow + (long)min(row0 + wave + 8 * i, M - 1) * ldo);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (not __syncthreads(): the loads above stay in flight)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int r = wave + 8 * i, rr = r & 127;
+            const uint2 v = *reinterpret_cast<const uint2*>(smem + (r >> 7) * PAIR + rr * 512 +
+                                                            (((lane >> 1) ^ (rr & 15)) << 4) + (lane & 1) * 8);
+            const float t0 = bf2f(v.x & 0xffff), t1 = bf2f(v.x >> 16), t2 = bf2f(v.y & 0xffff), t3 = bf2f(v.y >> 16);
+            float4 x;
+            if (EPI == EPI_RESID) {
+                x = xo[i % PF];
+                if (i + PF < 32)
+                    xo[i % PF] = *reinterpret_cast<const float4*>(orow + (long)min(row0 + r + 8 * PF, M - 1) * ldo);
+                x.x += t0 * g4.x;
+                x.y += t1 * g4.y;
+                x.z += t2 * g4.z;
+                x.w += t3 * g4.w;
+            } else {
+                x = make_float4(t0, t1, t2, t3);
+            }
+            if (row0 + r < M) *reinterpret_cast<float4*>(orow + (long)(row0 + r) * ldo) = x;
         }
     } else
 #pragma unroll
@@ -330,7 +394,10 @@ gemm256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict_
     const int per_xcd = (gridDim.x + 7) >> 3;
     for (int t = blockIdx.x >> 3; t < count; t += per_xcd) {
         gemm256_tile<EPI>(A, lda, W, ldw, bias, out, ldo, gate, M, N, K, tiles_m, tiles_n, GM, wide_store, first + t);
-        __syncthreads();          // the LDS buffers are staged again by the next tile
+        // the LDS buffers are staged again by the next tile: every wave's LDS reads have retired.  (Not
+        // __syncthreads(): that also waits for this tile's global stores, which may drain under the next tile's DMA.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -369,7 +436,8 @@ int ovd_impl_gemm256_bf16(const bf16_t* A, long lda, const bf16_t* W, long ldw, 
     int gm = ovd_env_int(gm_cache, "OVD_GEMM_GM", 4);
     if (gm <= 0) gm = 4;
     // 16-byte output stores need 16-byte aligned rows
-    const int wide = (ldo % 8 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
+    const int wide = ((epilogue == EPI_F32 || epilogue == EPI_RESID ? ldo % 4 == 0 : ldo % 8 == 0) &&
+                      reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 1 : 0;
     switch (epilogue) { GEMM_CASE(EPI_BF16) GEMM_CASE(EPI_BF16_GELU) GEMM_CASE(EPI_F32) GEMM_CASE(EPI_RESID) }
 #undef GEMM_CASE
     OVD_CHECK_LAUNCH("gemm256_bf16");

@@ -308,24 +308,24 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
         const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
         int frame = to, cch = co;
         if (a.til) { frame = 2 * to + co / C_out_row; cch = co % C_out_row; }
-        long off[16];
-        float rv[16];
+        const long fbase = (long)frame * a.Ho * a.Wo * C_out_row + cch;      // (a frame's offsets fit 32 bits: host check)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
-            const int ho = h0 + (ov >> tw_shift), wo = w0 + (ov & (TW - 1));
-            off[reg] = (cok && ho < a.Ho && wo < a.Wo) ? (((long)frame * a.Ho + ho) * a.Wo + wo) * C_out_row + cch : -1;
+        for (int half = 0; half < 2; ++half) {      // eight registers at a time: the loads in flight stay within the register budget
+            int off[8];
+            float rv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int reg = half * 8 + i;
+                const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
+                const int ho = h0 + (ov >> tw_shift), wo = w0 + (ov & (TW - 1));
+                off[i] = (cok && ho < a.Ho && wo < a.Wo) ? (ho * a.Wo + wo) * C_out_row : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rv[i] = a.resid ? a.resid[fbase + max(off[i], 0)] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (off[i] >= 0) a.out[fbase + off[i]] = acc[nb][half * 8 + i] + bv + rv[i];
         }
-        if (a.resid) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) rv[reg] = a.resid[max(off[reg], 0L)];
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) rv[reg] = 0.f;
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            if (off[reg] >= 0) a.out[off[reg]] = acc[nb][reg] + bv + rv[reg];
     }
 }
 
@@ -661,24 +661,24 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
         const int co = n0 + nb * 32 + (lane & 31);
         const bool cok = co < a.Cout;
         const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
-        long off[16];
-        float rv[16];
+        const long fbase = (long)to * a.Ho * a.Wo * a.Cout + co;      // (a frame's offsets fit 32 bits: host check)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
-            const int ho = h0 + (ov >> 4), wo = w0 + (ov & (WS_T - 1));
-            off[reg] = (cok && ho < a.Ho && wo < a.Wo) ? (((long)to * a.Ho + ho) * a.Wo + wo) * a.Cout + co : -1;
+        for (int half = 0; half < 2; ++half) {      // eight registers at a time: the loads in flight stay within the register budget
+            int off[8];
+            float rv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int reg = half * 8 + i;
+                const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
+                const int ho = h0 + (ov >> 4), wo = w0 + (ov & (WS_T - 1));
+                off[i] = (cok && ho < a.Ho && wo < a.Wo) ? (ho * a.Wo + wo) * a.Cout : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rv[i] = a.resid ? a.resid[fbase + max(off[i], 0)] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (off[i] >= 0) a.out[fbase + off[i]] = acc[nb][half * 8 + i] + bv + rv[i];
         }
-        if (a.resid) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) rv[reg] = a.resid[max(off[reg], 0L)];
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) rv[reg] = 0.f;
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            if (off[reg] >= 0) a.out[off[reg]] = acc[nb][reg] + bv + rv[reg];
     }
 }
 
@@ -856,6 +856,7 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
     if (upsample2) { HR = TH / 2 + 2; WR = TW / 2 + 2; }
     else { HR = (TH - 1) * stride_hw + KH; WR = (TW - 1) * stride_hw + KW; }
     OVD_REQUIRE(HR * WR <= MAX_HALO, "conv3d: halo too large");
+    OVD_REQUIRE((long)Ho * Wo * Cout < (1L << 31), "conv3d: an output frame must stay below 2^31 elements");
     // 32*nb output channels per workgroup: least padding; among equals 96 channels first (measured on
     // the decoder's 384-channel layers: 215 TFLOP/s against 180 with 128 and 181 with 64)
     int nb = 1;
