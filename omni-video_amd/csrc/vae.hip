@@ -353,14 +353,13 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
 #ifndef WS_ABL_RAW_HALO
 #define WS_ABL_RAW_HALO 0
 #endif
-#ifndef WS_ABL_NO_READS
-#define WS_ABL_NO_READS 0
-#endif
 #ifndef WS_ABL_NO_BARRIER
 #define WS_ABL_NO_BARRIER 0
 #endif
 constexpr int WS_T = 16;              // patch edge
 constexpr int WS_CONS = 8, WS_PROD = 4;
+constexpr int WS_LDV = 40;            // floats per staged row: 32 (bf16 hi | lo of 32 channels) + 8 pad; at 160 bytes
+                                      // the 16-row x four-k-block reads of a 16x16x32 fragment fall on 64 distinct banks
 constexpr int WS_HIT = 11;            // halo batches of 32 voxels per producer pass: up to 352 voxels (18 x 18 = 324)
 
 // Barrier between the taps: this wave's LDS traffic has retired, then s_barrier.  (A __syncthreads() also waits
@@ -405,9 +404,9 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
         HR = WS_T - 1 + a.KH; WR = WS_T - 1 + a.KW;
     }
     const int nvox = HR * WR;
-    const int halo_stride = WS_HIT * 32 * LDV;                      // floats per halo buffer (every producer batch has its rows)
-    float* const wt = lds + 2 * halo_stride;                        // 3 x [32*NB][LDV]
-    constexpr int WSLOT = 32 * NB * LDV;
+    const int halo_stride = WS_HIT * 32 * WS_LDV;                      // floats per halo buffer (every producer batch has its rows)
+    float* const wt = lds + 2 * halo_stride;                        // 3 x [32*NB][WS_LDV]
+    constexpr int WSLOT = 32 * NB * WS_LDV;
     const int nchunk = (a.Cin + 31) >> 5;
     const long frame_elems = (long)a.H * a.W * a.Cin;
     const long frame_vox = (long)a.H * a.W;
@@ -490,16 +489,16 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
                 return v;
             };
             auto w_store = [&](int slot, const WSet v) __attribute__((always_inline)) {
-                char* dst = reinterpret_cast<char*>(wt + slot * WSLOT + hv0 * LDV) + 16 * hj;
+                char* dst = reinterpret_cast<char*>(wt + slot * WSLOT + hv0 * WS_LDV) + 16 * hj;
                 *reinterpret_cast<float4*>(dst) = v.v0;
-                *reinterpret_cast<float4*>(dst + 16 * LDV * 4) = v.v1;
+                *reinterpret_cast<float4*>(dst + 16 * WS_LDV * 4) = v.v1;
                 if (NB > 1) {
-                    *reinterpret_cast<float4*>(dst + 32 * LDV * 4) = v.v2;
-                    *reinterpret_cast<float4*>(dst + 48 * LDV * 4) = v.v3;
+                    *reinterpret_cast<float4*>(dst + 32 * WS_LDV * 4) = v.v2;
+                    *reinterpret_cast<float4*>(dst + 48 * WS_LDV * 4) = v.v3;
                 }
                 if (NB > 2) {
-                    *reinterpret_cast<float4*>(dst + 64 * LDV * 4) = v.v4;
-                    *reinterpret_cast<float4*>(dst + 80 * LDV * 4) = v.v5;
+                    *reinterpret_cast<float4*>(dst + 64 * WS_LDV * 4) = v.v4;
+                    *reinterpret_cast<float4*>(dst + 80 * WS_LDV * 4) = v.v5;
                 }
             };
             Grp cur = grp(0);
@@ -559,7 +558,7 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
         };
         const bool has_norm = a.gamma != nullptr, has_silu = a.silu != 0;
         auto h_store = [&](const Grp& q, int buf, int it, float4 x, float rn, const float4& gm) __attribute__((always_inline)) {
-            float* dst = lds + buf * halo_stride + (hv0 + 16 * it) * LDV;
+            float* dst = lds + buf * halo_stride + (hv0 + 16 * it) * WS_LDV;
             if (PRE || WS_ABL_RAW_HALO) {
                 if (!PRE && hpix[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(reinterpret_cast<char*>(dst) + 16 * hj) = x;
@@ -610,74 +609,129 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
     }
 
     // ---------------------------------------------------------------------- consumers
-    const int iv = wave * 32 + (lane & 31);
-    const int dh = iv >> 4, dw = iv & (WS_T - 1);
-    const int kq = lane >> 5;
-    f32x16 acc[NB];
+    // v_mfma_f32_16x16x32_bf16 with the weights as the A operand (rows = 16 output channels) and the voxels as B
+    // (columns = 16 voxels = one patch row): lane holds A[row lane % 16][k (lane / 16) * 8 .. + 7], B[k ...][column
+    // lane % 16] and D[rows (lane / 16) * 4 .. + 3][column lane % 16], i.e. four consecutive output channels of one voxel.
+    // (The same FLOPs issued as 32x32x16 instructions hold a shader clock of 1.91 GHz against 2.2 GHz for these: the
+    // kernel runs at the power limit, and the narrow instruction costs less energy per product.)
+    const int l16 = lane & 15, kb = lane >> 4;
+    constexpr int NCB = 2 * NB;         // blocks of 16 output channels
+    f32x4 acc[2][NCB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int vb = 0; vb < 2; ++vb)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[nb][j] = 0.f;
+        for (int cb = 0; cb < NCB; ++cb) acc[vb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Fragments are read ahead of their use in two stages per tap, pinned by scheduling barriers (left alone, hipcc
+    // re-uses one register set for successive weight fragments: read, wait, two MFMAs, read, wait ...).  While the
+    // first NB channel blocks of tap t are multiplied, the second NB are in flight; while those are multiplied, the
+    // voxels and the first NB blocks of tap t + 1 - whose weight slice and halo are complete at tap t's barrier.  The
+    // first tap of a group reads its voxels behind the barrier (the halo's last rows are written in the tap before).
+    struct XFrag { bf16x8 h[2], l[2]; };
+    struct WFrag { bf16x8 h[NB], l[NB]; };
+    auto read_x = [&](const float* halo, int t) __attribute__((always_inline)) {
+        XFrag x;
+        const int kh = t / 3, kw = t % 3;
+#pragma unroll
+        for (int vb = 0; vb < 2; ++vb) {        // voxel block vb: patch row 2 * wave + vb, columns 0 .. 15
+            const int dh = 2 * wave + vb;
+            int hsrc, wsrc;
+            if (a.ups) { hsrc = ((h0 + dh + kh - 1) >> 1) - hs0; wsrc = ((w0 + l16 + kw - 1) >> 1) - ws0; }
+            else { hsrc = dh + kh; wsrc = l16 + kw; }
+            const char* xc = reinterpret_cast<const char*>(halo + (hsrc * WR + wsrc) * WS_LDV) + 16 * kb;
+            x.h[vb] = *reinterpret_cast<const bf16x8*>(xc);
+            x.l[vb] = *reinterpret_cast<const bf16x8*>(xc + 64);
+        }
+        return x;
+    };
+    const char* const wlane = reinterpret_cast<const char*>(wt + l16 * WS_LDV) + 16 * kb;
+    auto read_w = [&](int slot, int cb0) __attribute__((always_inline)) {
+        WFrag w;
+        const char* wc = wlane + (slot * WSLOT + cb0 * 16 * WS_LDV) * 4;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            w.h[i] = *reinterpret_cast<const bf16x8*>(wc + i * 16 * WS_LDV * 4);
+            w.l[i] = *reinterpret_cast<const bf16x8*>(wc + i * 16 * WS_LDV * 4 + 64);
+        }
+        return w;
+    };
+    auto mma = [&](int cb0, const WFrag& w, const XFrag& x) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            // per accumulator: x_lo * w_hi, x_hi * w_lo, x_hi * w_hi (small terms first)
+            acc[0][cb0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[i], x.l[0], acc[0][cb0 + i], 0, 0, 0);
+            acc[1][cb0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[i], x.l[1], acc[1][cb0 + i], 0, 0, 0);
+            acc[0][cb0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[i], x.h[0], acc[0][cb0 + i], 0, 0, 0);
+            acc[1][cb0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[i], x.h[1], acc[1][cb0 + i], 0, 0, 0);
+            acc[0][cb0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[i], x.h[0], acc[0][cb0 + i], 0, 0, 0);
+            acc[1][cb0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[i], x.h[1], acc[1][cb0 + i], 0, 0, 0);
+        }
+    };
+    XFrag x0, x1;
+    WFrag wa, wb;
     for (int g = 0; g < G; ++g) {
         const float* halo = lds + (g & 1) * halo_stride;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            ws_tap_barrier();
-            const int kh = t / 3, kw = t % 3;
-            int hsrc, wsrc;
-            if (a.ups) { hsrc = ((h0 + dh + kh - 1) >> 1) - hs0; wsrc = ((w0 + dw + kw - 1) >> 1) - ws0; }
-            else { hsrc = dh + kh; wsrc = dw + kw; }
-            const char* ac = reinterpret_cast<const char*>(halo + (hsrc * WR + wsrc) * LDV + 4 * kq);
-            const char* bc = reinterpret_cast<const char*>(wt + (t % 3) * WSLOT + (lane & 31) * LDV + 4 * kq);
-            if (WS_ABL_NO_READS) {      // timing only: operands from two reads per tap instead of sixteen
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ac), bh = *reinterpret_cast<const bf16x8*>(bc);
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nb], 0, 0, 0);
-                continue;
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ac + 32 * ks);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ac + 64 + 32 * ks);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bc + nb * 32 * LDV * 4 + 32 * ks);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bc + nb * 32 * LDV * 4 + 64 + 32 * ks);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nb], 0, 0, 0);
-                }
-            }
+#define WS_CONSUMER_TAP(T, XCUR, XNEXT)                                                                   \
+        {                                                                                                  \
+            ws_tap_barrier();                                                                              \
+            if ((T) == 0) {                                                                                \
+                XCUR = read_x(halo, 0);                                                                    \
+                if (g == 0) wa = read_w(0, 0);                                                             \
+            }                                                                                              \
+            wb = read_w((T) % 3, NB);                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            mma(0, wa, XCUR);                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if ((T) < 8) XNEXT = read_x(halo, (T) + 1);                                                    \
+            wa = read_w(((T) + 1) % 3, 0);       /* tap 8: the next group's first slice (slot 0) */       \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            mma(NB, wb, XCUR);                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
         }
+        WS_CONSUMER_TAP(0, x0, x1) WS_CONSUMER_TAP(1, x1, x0) WS_CONSUMER_TAP(2, x0, x1)
+        WS_CONSUMER_TAP(3, x1, x0) WS_CONSUMER_TAP(4, x0, x1) WS_CONSUMER_TAP(5, x1, x0)
+        WS_CONSUMER_TAP(6, x0, x1) WS_CONSUMER_TAP(7, x1, x0) WS_CONSUMER_TAP(8, x0, x1)
+#undef WS_CONSUMER_TAP
     }
     MFMA_DRAIN();
-    // Epilogue: the residual values of a 32-channel block are all fetched before the first store (out and resid may be
-    // one buffer as far as the compiler knows, so a load placed after a store would wait for it: sixteen memory
-    // round trips in a row per block instead of one).
+    // Epilogue, one patch row (16 voxels) at a time: lane holds channels n0 + cb * 16 + kb * 4 .. + 3 of voxel l16.  The
+    // residual values of a row are all requested before its first store (out and resid may be one buffer as far as
+    // the compiler knows, so a load placed after a store would wait for it: one memory round trip per block).
+    const bool vec = (a.Cout & 3) == 0;         // 16-byte accesses need whole groups of four channels
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int co = n0 + nb * 32 + (lane & 31);
-        const bool cok = co < a.Cout;
-        const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
-        const long fbase = (long)to * a.Ho * a.Wo * a.Cout + co;      // (a frame's offsets fit 32 bits: host check)
+    for (int vb = 0; vb < 2; ++vb) {
+        const int ho = h0 + 2 * wave + vb, wo = w0 + l16;
+        const bool vok = ho < a.Ho && wo < a.Wo;
+        const long obase = (((long)to * a.Ho + min(ho, a.Ho - 1)) * a.Wo + min(wo, a.Wo - 1)) * a.Cout;
+        if (vec) {
+            float4 rv[NCB];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {      // eight registers at a time: the loads in flight stay within the register budget
-            int off[8];
-            float rv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int reg = half * 8 + i;
-                const int ov = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
-                const int ho = h0 + (ov >> 4), wo = w0 + (ov & (WS_T - 1));
-                off[i] = (cok && ho < a.Ho && wo < a.Wo) ? (ho * a.Wo + wo) * a.Cout : -1;
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int co = min(n0 + cb * 16 + kb * 4, a.Cout - 4);
+                rv[cb] = a.resid ? *reinterpret_cast<const float4*>(a.resid + obase + co) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rv[i] = a.resid ? a.resid[fbase + max(off[i], 0)] : 0.f;
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int co = n0 + cb * 16 + kb * 4;
+                if (!vok || co >= a.Cout) continue;
+                const float4 bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 y;
+                y.x = acc[vb][cb][0] + bv.x + rv[cb].x;
+                y.y = acc[vb][cb][1] + bv.y + rv[cb].y;
+                y.z = acc[vb][cb][2] + bv.z + rv[cb].z;
+                y.w = acc[vb][cb][3] + bv.w + rv[cb].w;
+                *reinterpret_cast<float4*>(a.out + obase + co) = y;
+            }
+        } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (off[i] >= 0) a.out[fbase + off[i]] = acc[nb][half * 8 + i] + bv + rv[i];
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = n0 + cb * 16 + kb * 4 + i;
+                    if (!vok || co >= a.Cout) continue;
+                    float y = acc[vb][cb][i] + (a.bias ? a.bias[co] : 0.f);
+                    if (a.resid) y += a.resid[obase + co];
+                    a.out[obase + co] = y;
+                }
         }
     }
 }
@@ -905,7 +959,7 @@ int ovd_impl_conv3d_cl(const float* x, const float* prev2, const float* prev1, c
         const int t16 = ((a.Wo + WS_T - 1) / WS_T) * ((a.Ho + WS_T - 1) / WS_T) * To;
         int nbw = nb == 4 ? 2 : nb;          // (128 channels per workgroup would spill the producers' registers)
         if (nbw > 1 && (long)t16 * ceil_div(Cout, 32 * nbw) < (long)cus) nbw = 1;
-        const size_t lds_ws = (size_t)(2 * WS_HIT * 32 + 3 * 32 * nbw) * LDV * sizeof(float);
+        const size_t lds_ws = (size_t)(2 * WS_HIT * 32 + 3 * 32 * nbw) * WS_LDV * sizeof(float);
         dim3 gridw(t16, ceil_div(Cout, 32 * nbw)), blkw(64 * (WS_CONS + WS_PROD));
 #define WS_CASE(NBV, PREV)                                                                                   \
     case NBV: {                                                                                              \
