@@ -137,7 +137,7 @@ __device__ __forceinline__ void k_tile64(f32x4 (&acc)[4][8], char* smem, int buf
     }
     if (TAIL < 2) stage_half<1>(sa, kb1, oth);
     phase_open<TAIL == 2 ? 0 : 8>();
-    if (TAIL == 2 && bias_lane != nullptr) {
+    if (TAIL == 2) {
         // Inline assembly, so that the compiler keeps no books on these loads: one it knows to be pending makes it
         // drain the DMA queue (s_waitcnt vmcnt(0)) wherever its register shuffling touches the destination.  Nothing
         // else is in flight here (the wait above was vmcnt(0)); the epilogue waits for them itself.
@@ -223,8 +223,10 @@ gemm256_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ 
     k_tile64<1>(acc, smem, t & 1, (long)(t + 1) * 128, 0, sa, sw, lo0, lo1, a_rd, w_rd, wave);
     ++t;
     // bias of this lane's 16 output columns: n = col0 + (nt >> 1) * 128 + wc * 32 + (nt & 1) * 16 + fq * 4
-    unsigned long long bias_q[4] = {0ull, 0ull, 0ull, 0ull};
-    k_tile64<2>(acc, smem, t & 1, 0, 0, sa, sw, lo0, lo1, a_rd, w_rd, wave, bias ? bias + col0 + wc * 32 + fq * 4 : nullptr,
+    // (without a bias the loads read the weights instead - any valid address - and the values are dropped: no branch
+    // around inline assembly whose results the compiler cannot see arriving)
+    unsigned long long bias_q[4];
+    k_tile64<2>(acc, smem, t & 1, 0, 0, sa, sw, lo0, lo1, a_rd, w_rd, wave, (bias ? bias : W) + col0 + wc * 32 + fq * 4,
                 bias_q);
     if (wr == 0) __builtin_amdgcn_s_barrier();            // balances the extra barrier above
     // the bias values have landed; the registers are operands so that no use of them can be scheduled above the wait
@@ -235,7 +237,7 @@ gemm256_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ 
     float bv[4][4], gv[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const uint32_t blo = (uint32_t)bias_q[nt], bhi = (uint32_t)(bias_q[nt] >> 32);
+        const uint32_t blo = bias ? (uint32_t)bias_q[nt] : 0u, bhi = bias ? (uint32_t)(bias_q[nt] >> 32) : 0u;
         bv[nt][0] = bf2f(blo & 0xffff);
         bv[nt][1] = bf2f(blo >> 16);
         bv[nt][2] = bf2f(bhi & 0xffff);

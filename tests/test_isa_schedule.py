@@ -117,6 +117,38 @@ def test_phased_gemm_loop_keeps_its_order(tmp_path, src, kernel, mfma, count):
         assert tail == want_tail, (name, tail)
 
 
+def registers(token_text):
+    """VGPR numbers named in an operand string: v12, v[8:11]."""
+    regs = set()
+    for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", token_text):
+        regs.update(range(int(lo), int(hi) + 1))
+    regs.update(int(n) for n in re.findall(r"\bv(\d+)\b", token_text))
+    return regs
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_gemm_bias_loads_hidden_from_the_compiler_are_not_touched_before_their_wait(tmp_path):
+    """The bias values of the 256 x 256 GEMM are fetched by inline assembly inside the last K-tile (the compiler
+    keeps no books on them) and waited for by an `s_waitcnt vmcnt(0)` in front of the epilogue.  Nothing the compiler
+    emits in between may read or write the destination registers: a copy made before the data has landed would
+    carry garbage and no test of values is guaranteed to see it."""
+    ks = kernels(listing("gemm256.hip", tmp_path), "gemm256_kernel")
+    assert len(ks) == 4, sorted(ks)
+    for name, body in ks.items():
+        lines = [ln.split(";")[0].strip() for ln in body.split("\n")]
+        loads = [i for i, ln in enumerate(lines) if ln.startswith("global_load_dwordx2")]
+        assert len(loads) == 4, (name, len(loads))
+        dest = set()
+        for i in loads:
+            dest |= registers(lines[i].split(",")[0])
+        assert len(dest) == 8, (name, sorted(dest))
+        wait = next(i for i in range(loads[-1], len(lines)) if lines[i] == "s_waitcnt vmcnt(0)")
+        for ln in lines[loads[-1] + 1:wait]:
+            if not ln or ln.endswith(":") or ln.startswith((".", "s_")):
+                continue
+            assert not (registers(ln) & dest), (name, ln)
+
+
 def main_loop(body):
     """Lines of the loop (label ... backward branch to it) that holds the most MFMAs; the shortest such loop."""
     lines = body.split("\n")
