@@ -1,6 +1,7 @@
-"""Development aid: runs the cfg2 VAE decode in a loop for a few seconds while a thread polls rocm-smi for the
-shader clock and the socket power; prints the median / min / max of both and the decode time.
-usage: python tools/clock_sample.py [seconds]"""
+"""Development aid: runs one workload in a loop for a few seconds while a thread polls rocm-smi for the shader
+clock; prints the median / min / max and the time per iteration.  Workloads: vae (cfg2 decode, default), attn
+(self-attention at the cfg2 shape), gemm (the FFN-up GEMM of the 1.3B model with its GELU epilogue), gemmqkv.
+usage: python tools/clock_sample.py [seconds] [workload]"""
 import os
 import re
 import subprocess
@@ -26,20 +27,40 @@ def poll(stop, rows):
         time.sleep(0.3)
 
 
+def workload(name):
+    if name == "vae":
+        from omnivideo.modules.vae2_1 import Wan2_1_VAE
+        with torch.device("cuda"):
+            v = Wan2_1_VAE(z_dim=16, vae_pth=None, device="cuda")
+        z = torch.randn(16, 13, 60, 104, device="cuda")
+        return lambda: v.decode([z])
+    import omnivideo._hip as H
+    bf = torch.bfloat16
+    if name == "attn":
+        B, L, N, D = 2, 20280, 12, 128
+        q, k, v = (torch.randn(B, L, N, D, device="cuda").to(bf) for _ in range(3))
+        o = torch.empty_like(q)
+        return lambda: [H.flash_attn(q, k, v, o) for _ in range(20)]
+    M, N, K, epi = (40560, 8960, 1536, 1) if name == "gemm" else (40560, 4608, 1536, 0)
+    a = torch.randn(M, K, device="cuda").to(bf)
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(bf)
+    b = torch.randn(N, device="cuda").to(bf)
+    out = torch.empty(M, N, device="cuda", dtype=bf)
+    return lambda: [H.gemm(a, w, out, b, epi) for _ in range(100)]
+
+
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
-    from omnivideo.modules.vae2_1 import Wan2_1_VAE
-    with torch.device("cuda"):
-        v = Wan2_1_VAE(z_dim=16, vae_pth=None, device="cuda")
-    z = torch.randn(16, 13, 60, 104, device="cuda")
-    v.decode([z])
+    name = sys.argv[2] if len(sys.argv) > 2 else "vae"
+    step = workload(name)
+    step()
     torch.cuda.synchronize()
     stop, rows = threading.Event(), []
     th = threading.Thread(target=poll, args=(stop, rows))
     th.start()
     t0, n = time.time(), 0
     while time.time() - t0 < secs:
-        v.decode([z])
+        step()
         torch.cuda.synchronize()
         n += 1
     dt = (time.time() - t0) / n
@@ -47,7 +68,7 @@ def main():
     th.join()
     clk = sorted(r[0] for r in rows if r[0])
     pw = sorted(r[1] for r in rows if len(r) > 1 and r[1])
-    print(f"decode {dt:.3f} s x {n}; samples {len(rows)}")
+    print(f"{name}: {dt:.4f} s per iteration x {n}; samples {len(rows)}")
     if clk:
         print(f"sclk MHz median {clk[len(clk) // 2]} min {clk[0]} max {clk[-1]}")
     if pw:
