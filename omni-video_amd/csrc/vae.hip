@@ -331,30 +331,27 @@ __global__ void __launch_bounds__(256) conv3d_cl_kernel(const ConvArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Producer / consumer form of the 3x3 stride-1 convolutions (split-bf16 products, pre-split weights): the same
-// arithmetic and the same LDS images as conv3d_cl_kernel<NB, true>, with the two halves of its work given to
+// products and the same accumulation order per output element as conv3d_cl_kernel<NB, true> (x_lo w_hi, x_hi w_lo,
+// x_hi w_hi per 32-channel chunk, chunks and taps in the same order), with the two halves of its work given to
 // different waves so that they overlap instead of alternating.
-//   * 8 consumer waves own 32 output voxels each of a 16 x 16 patch (256 voxels x 32*NB channels per workgroup):
-//     per tap they read their operand fragments from LDS and issue the NB*6 MFMAs - nothing else.
-//   * 4 producer waves do what conv3d_cl_kernel does between its barriers: they fetch the halo patch of the NEXT
-//     (time tap, 32-channel chunk) group from the activation tensor, apply the voxel norm / gamma / SiLU, split into
-//     bf16 hi | lo and write it to the other halo buffer, a few voxels per tap; and they copy the weight slice of
-//     the tap after next into a ring of three slots.  Every global load is issued one tap before its value is
-//     written to LDS, so a producer never waits for memory inside a tap.
+//   * 8 consumer waves own two patch rows (2 x 16 voxels) each of a 16 x 16 patch (256 voxels x 32*NB channels per
+//     workgroup): per tap they read their operand fragments from LDS and issue the NB*12 MFMAs - nothing else.
+//   * 4 producer waves do what conv3d_cl_kernel does between its barriers.  Two of them fetch the halo patch of the
+//     NEXT (time tap, 32-channel chunk) group - from the pre-split image (PRE: pure copies), or from the fp32
+//     activation tensor, applying voxel norm / gamma / SiLU and the split into bf16 hi | lo - and write it to the
+//     other halo buffer, a few voxels per tap; the other two copy the weight slice of the tap after next into a ring of
+//     three slots.  Every global load is issued three taps before its value is written to LDS, so a producer does not
+//     wait for memory inside a tap; the roles are separate waves because a wave's loads return in order as far as
+//     its counter can tell, and the L2-resident weight slices would otherwise queue behind the halo's HBM latency.
 // One barrier per tap joins the two sides: after barrier j the slot of tap j and (first tap of a group) the
 // group's halo are complete, and the slot of tap j - 1 and the previous group's halo buffer are free.
 // A group whose frame is temporal zero padding is skipped (as in conv3d_cl_kernel).
-// timing-only ablations of the producers (builds under build_variants/; results are wrong when set)
+// timing-only ablations of the producers (tools/build_variant.sh ... -DWS_ABL_NO_HALO=1; results are wrong when set)
 #ifndef WS_ABL_NO_WEIGHTS
 #define WS_ABL_NO_WEIGHTS 0
 #endif
 #ifndef WS_ABL_NO_HALO
 #define WS_ABL_NO_HALO 0
-#endif
-#ifndef WS_ABL_RAW_HALO
-#define WS_ABL_RAW_HALO 0
-#endif
-#ifndef WS_ABL_NO_BARRIER
-#define WS_ABL_NO_BARRIER 0
 #endif
 constexpr int WS_T = 16;              // patch edge
 constexpr int WS_CONS = 8, WS_PROD = 4;
@@ -366,7 +363,6 @@ constexpr int WS_HIT = 11;            // halo batches of 32 voxels per producer 
 // for every global load the wave has in flight - the producers' fetches for later taps - and would put the
 // memory latency back into every tap.)
 __device__ __forceinline__ void ws_tap_barrier() {
-    if (WS_ABL_NO_BARRIER) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -559,8 +555,7 @@ __global__ void __launch_bounds__(768) conv3d_ws_kernel(const ConvArgs a) {
         const bool has_norm = a.gamma != nullptr, has_silu = a.silu != 0;
         auto h_store = [&](const Grp& q, int buf, int it, float4 x, float rn, const float4& gm) __attribute__((always_inline)) {
             float* dst = lds + buf * halo_stride + (hv0 + 16 * it) * WS_LDV;
-            if (PRE || WS_ABL_RAW_HALO) {
-                if (!PRE && hpix[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PRE) {      // (out-of-frame voxels arrive as zeros: the descriptor's range check)
                 *reinterpret_cast<float4*>(reinterpret_cast<char*>(dst) + 16 * hj) = x;
                 return;
             }
