@@ -734,8 +734,25 @@ def main():
                 vae = Wan2_1_VAE(z_dim=16, vae_pth=None, device=dev)
         z = torch.randn(*wl["latent"], device=dev, generator=g)
         comm = make_group_comm(sp_group, "auto") if sp else None       # row-sharded decode over the group
+        vae_flop = [0.0]
         with torch.no_grad():
-            vae.decode([z], comm=comm)           # under sequence parallelism: row-sharded over the group
+            # the untimed first decode also counts the convolutions' FLOPs (2 x output voxels x taps x Cin x Cout, as
+            # fp32 work) through the two wrappers every convolution of the VAE goes through
+            import omnivideo.modules.vae2_1 as vae_mod
+            conv_plain, conv_split = vae_mod.H.vae_conv3d, vae_mod.H.vae_conv3d_ps
+
+            def counted(fn):
+                def run(x, w, *a, **kw):
+                    y = fn(x, w, *a, **kw)
+                    taps, cout, cin = w.shape
+                    vae_flop[0] += 2.0 * (y.numel() / y.shape[-1]) * taps * cout * cin
+                    return y
+                return run
+            vae_mod.H.vae_conv3d, vae_mod.H.vae_conv3d_ps = counted(conv_plain), counted(conv_split)
+            try:
+                vae.decode([z], comm=comm)       # under sequence parallelism: row-sharded over the group
+            finally:
+                vae_mod.H.vae_conv3d, vae_mod.H.vae_conv3d_ps = conv_plain, conv_split
             fence()
             t0 = time.perf_counter()
             vae.decode([z], comm=comm)
@@ -804,6 +821,14 @@ def main():
             out["vae_encode_s_per_video"] = round(vae_enc_s, 3)
         if vae_s is not None:
             out["vae_decode_s_per_video"] = round(vae_s, 3)
+            if not sp and vae_flop[0] > 0:
+                # every fp32 product of the convolutions is three bf16 MFMA products of hi / lo operand halves
+                ach = 3.0 * vae_flop[0] / vae_s / 1e12
+                out["roofline_vae"] = {"bound": "mfma", "kernel": "whole VAE decode (conv3d_ws_kernel holds 85 % of its FLOPs)",
+                                       "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(ach / PEAK_BF16_TFLOPS, 4), "fp32_flop_per_decode": vae_flop[0],
+                                       "note": "split-bf16 arithmetic: 3 bf16 MFMA products per fp32 product; wall time of "
+                                               "the decode, all kernels included"}
             out["value_with_vae_decode"] = round(videos * wl["frames"] / (wl["steps"] * ms_step * 1e-3 + ctx_s + vae_s), 4) if sp_ok else None
             if vae_enc_s is not None:        # V2V: encode of the source clip + loop + decode
                 out["value_with_vae"] = round(videos * wl["frames"] / (wl["steps"] * ms_step * 1e-3 + ctx_s + vae_s + vae_enc_s), 4) if sp_ok else None
