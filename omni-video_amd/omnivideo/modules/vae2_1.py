@@ -291,15 +291,12 @@ class _Runner:
         L = Hh * Ww
         if L % 4:
             raise NotImplementedError("VAE attention needs h*w to be a multiple of 4")
-        _, bq, _ = self.weight(blk.to_qkv)
-        wq = self.weight_f32(blk.to_qkv)
+        wqkv, bq, _ = self.weight(blk.to_qkv)
         rn = H.vae_voxel_rnorm(x)
         gamma = blk.norm.gamma.detach().reshape(-1).to(F32).contiguous()
-        parts = []
-        for i in range(3):
-            parts.append(H.vae_conv3d(x, wq[:, i * C:(i + 1) * C].contiguous(), bq[i * C:(i + 1) * C].contiguous(),
-                                      (1, 1, 1), rnorm=rn, gamma=gamma))
-        q, k, v = parts
+        # q | k | v in one launch (every output channel is its own dot product: the same values as three launches)
+        qkv = H.vae_conv3d(x, wqkv, bq, (1, 1, 1), rnorm=rn, gamma=gamma)
+        q, k, v = (qkv[..., i * C:(i + 1) * C].contiguous() for i in range(3))
         wp, bp, _ = self.weight(blk.proj)
         out = torch.empty_like(x)
         for t in range(T):
